@@ -1,0 +1,279 @@
+"""Generate the golden fixtures in this directory from the reference implementation.
+
+Runs ONLY in the build container (it imports /root/reference/src).  Tests never
+import this script; the committed ``*.npz`` files are the interface.
+
+    python tests/golden/make_golden.py
+
+What is imported from the reference: utils/hermitian.py (numpy + scipy only) and
+layer/sparse_magnet.py (needs a stub for its unused ``torch_sparse`` import) and
+utils/edge_data.in_out_degree (needs attribute-bag stubs for torch_geometric,
+torch_scatter).  Every array stored is either an input we made up (seeded) or an
+output of a reference function; no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(REF, 'src'))
+    for name in ['torch_sparse', 'torch_scatter', 'torch_geometric', 'torch_geometric.data',
+                 'torch_geometric.utils', 'torch_geometric.datasets', 'torch_geometric.transforms',
+                 'torch_geometric.nn', 'torch_geometric.nn.conv', 'torch_geometric.nn.inits']:
+        m = types.ModuleType(name)
+        m.__getattr__ = lambda attr: object      # any attribute resolves to a dummy
+        sys.modules[name] = m
+    from utils.hermitian import hermitian_decomp_sparse, cheb_poly_sparse
+    from layer.sparse_magnet import ChebConv, ChebNet, ChebNet_Edge
+    return hermitian_decomp_sparse, cheb_poly_sparse, ChebConv, ChebNet, ChebNet_Edge
+
+
+def to_coo_lists(L):
+    """scipy list -> (L_real, L_imag) torch COO lists, as src/sparse_Magnet.py:55-62,108-112."""
+    def conv(mx):
+        mx = mx.tocoo().astype(np.float32)
+        idx = torch.from_numpy(np.vstack((mx.row, mx.col)).astype(np.int64))
+        return torch.sparse_coo_tensor(idx, torch.from_numpy(mx.data), torch.Size(mx.shape))
+    return [conv(l.real) for l in L], [conv(l.imag) for l in L]
+
+
+def lap_cases(ref_h):
+    rng = np.random.default_rng(1234)
+    tele = sp.load_npz(os.path.join(REF, 'dataset/data/tmp/telegram/telegram_adj.npz')).tocoo()
+    cases = []
+
+    def add(name, row, col, n, q, w=None, max_eigen=2.0, gcn=False):
+        cases.append(dict(name=name, row=np.asarray(row, np.int64), col=np.asarray(col, np.int64),
+                          n=n, q=q, w=w, max_eigen=max_eigen, gcn=gcn))
+
+    add('telegram_unweighted_q25', tele.row, tele.col, 245, 0.25)
+    add('telegram_weighted_q05', tele.row, tele.col, 245, 0.05, tele.data.astype(np.int64))
+    add('telegram_weighted_q15', tele.row, tele.col, 245, 0.15, tele.data.astype(np.int64))
+    add('telegram_unweighted_q0', tele.row, tele.col, 245, 0.0)
+    # adversarial: duplicates, self-loops, reciprocal equal / unequal weights, isolated nodes
+    row = [0, 0, 0, 1, 2, 2, 3, 3, 4, 1, 5, 5, 6]
+    col = [1, 1, 2, 0, 2, 3, 2, 3, 0, 0, 6, 6, 5]
+    add('tiny_unweighted', row, col, 9, 0.25)
+    add('tiny_weighted', row, col, 9, 0.1, np.array([1, 2, 3, 3, 5, 2, 2, 1, 4, 1, 1, 1, 2], np.int64))
+    add('tiny_q50', row, col, 9, 0.5)
+    add('tiny_lambda3', row, col, 9, 0.25, None, 3.0)
+    add('tiny_gcn_appr', row, col, 9, 0.25, None, 2.0, True)
+    add('empty_graph', [], [], 4, 0.25)
+    add('only_self_loops', [0, 1, 2], [0, 1, 2], 3, 0.25)
+    for t, q in enumerate([0.0, 0.1, 0.25, 0.2]):
+        n = int(rng.integers(20, 400)); e = int(rng.integers(50, 5000))
+        r = rng.integers(0, n, e); c = rng.integers(0, n, e)
+        w = None if t % 2 == 0 else rng.integers(1, 30, e).astype(np.int64)
+        add('random%d' % t, r, c, n, q, w)
+    n, e = 150, 2500
+    r = rng.integers(0, n, e); c = rng.integers(0, n, e)
+    add('random_float_weights', r, c, n, 0.25, rng.random(e).astype(np.float32))
+    add('random_lambda3_weighted', r, c, n, 0.1, rng.integers(1, 9, e).astype(np.int64), 3.0)
+
+    out = {'names': np.array([c['name'] for c in cases])}
+    for c in cases:
+        L = ref_h(c['row'], c['col'], c['n'], c['q'], True, True, c['max_eigen'], c['gcn'], c['w']).tocsr()
+        L.sort_indices()
+        k = c['name']
+        out[k + '/row'] = c['row']; out[k + '/col'] = c['col']
+        out[k + '/params'] = np.array([c['n'], c['q'], c['max_eigen'], float(c['gcn'])], np.float64)
+        if c['w'] is not None:
+            out[k + '/w'] = c['w']
+        out[k + '/indptr'] = L.indptr.astype(np.int32)
+        out[k + '/indices'] = L.indices.astype(np.int32)
+        out[k + '/data'] = L.data.astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, 'lap_cases.npz'), **out)
+    print('lap_cases:', len(cases), 'cases')
+
+
+def cheb_cases(ref_h, ref_c):
+    tele = sp.load_npz(os.path.join(REF, 'dataset/data/tmp/telegram/telegram_adj.npz')).tocoo()
+    out = {}
+    for name, q, w in [('unw_q25', 0.25, None), ('w_q05', 0.05, tele.data.astype(np.int64))]:
+        L = ref_h(tele.row, tele.col, 245, q, True, True, 2.0, False, w)
+        T = ref_c(L, 3)
+        for k in (2, 3):
+            t = T[k].tocsr(); t.sort_indices()
+            out['%s/T%d/indptr' % (name, k)] = t.indptr.astype(np.int32)
+            out['%s/T%d/indices' % (name, k)] = t.indices.astype(np.int32)
+            out['%s/T%d/data' % (name, k)] = t.data.astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, 'cheb_poly_cases.npz'), **out)
+    print('cheb_poly_cases written')
+
+
+def _graph_telegram(ref_h, ref_c, q, K, weighted=False):
+    tele = sp.load_npz(os.path.join(REF, 'dataset/data/tmp/telegram/telegram_adj.npz')).tocoo()
+    w = tele.data.astype(np.int64) if weighted else None
+    L = ref_c(ref_h(tele.row, tele.col, 245, q, True, True, 2.0, False, w), K)
+    return tele.row.astype(np.int64), tele.col.astype(np.int64), w, L
+
+
+def conv_cases(ref_h, ref_c, ChebConv):
+    out = {}
+    names = []
+    for K, cin, cout, q, weighted in [(1, 5, 7, 0.25, False), (2, 8, 4, 0.1, False),
+                                      (3, 4, 16, 0.05, True), (2, 1, 16, 0.1, False),
+                                      (0, 6, 3, 0.25, False)]:
+        name = 'K%d_%dto%d' % (K, cin, cout)
+        names.append(name)
+        row, col, w, L = _graph_telegram(ref_h, ref_c, q, K, weighted)
+        Lr, Li = to_coo_lists(L)
+        torch.manual_seed(100 + K)
+        conv = ChebConv(cin, cout, K, Lr, Li)
+        with torch.no_grad():
+            conv.bias.uniform_(-0.5, 0.5)
+        Xr = torch.randn(245, cin, requires_grad=True)
+        Xi = torch.randn(245, cin, requires_grad=True)
+        Gr = torch.randn(245, cout); Gi = torch.randn(245, cout)
+        real, imag = conv((Xr, Xi))
+        loss = (real * Gr).sum() + (imag * Gi).sum()
+        loss.backward()
+        out[name + '/params'] = np.array([K, cin, cout, q, float(weighted)], np.float64)
+        for k, v in [('weight', conv.weight), ('bias', conv.bias), ('Xr', Xr), ('Xi', Xi), ('Gr', Gr), ('Gi', Gi),
+                     ('real', real), ('imag', imag), ('dweight', conv.weight.grad), ('dbias', conv.bias.grad),
+                     ('dXr', Xr.grad), ('dXi', Xi.grad)]:
+            out[name + '/' + k] = v.detach().numpy().copy()
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'conv_cases.npz'), **out)
+    print('conv_cases:', names)
+
+
+def net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge):
+    out = {}
+    names = []
+    rng = np.random.default_rng(7)
+    labels = np.load(os.path.join(REF, 'dataset/data/tmp/telegram/telegram_labels.npy'), allow_pickle=False)
+    labels = (labels - labels.min()).astype(np.int64).ravel()[:245]
+    for tag, K, layer, act, F, q in [('a', 1, 2, True, 16, 0.25), ('b', 2, 2, True, 16, 0.1),
+                                     ('c', 2, 3, False, 8, 0.1), ('d', 3, 1, True, 4, 0.05)]:
+        row, col, w, L = _graph_telegram(ref_h, ref_c, q, K)
+        Lr, Li = to_coo_lists(L)
+        cin = 6
+        X = torch.randn(245, cin, generator=torch.Generator().manual_seed(50))
+        # ---- node classification (ChebNet) ----
+        name = 'node_' + tag; names.append(name)
+        torch.manual_seed(200 + K + layer)
+        net = ChebNet(cin, Lr, Li, num_filter=F, K=K, label_dim=int(labels.max()) + 1, activation=act,
+                      layer=layer, dropout=0.0)
+        for m in net.Chebs:
+            if hasattr(m, 'bias'):
+                with torch.no_grad():
+                    m.bias.uniform_(-0.3, 0.3)
+        Xr = X.clone().requires_grad_(True); Xi = X.clone().requires_grad_(True)
+        train = torch.from_numpy(rng.random(245) < 0.6)
+        preds = net(Xr, Xi)
+        y = torch.from_numpy(labels[None])
+        loss = torch.nn.NLLLoss()(preds[:, :, train], y[:, train])
+        loss.backward()
+        out[name + '/params'] = np.array([K, layer, float(act), F, q, cin], np.float64)
+        out[name + '/X'] = X.numpy(); out[name + '/train'] = train.numpy(); out[name + '/y'] = labels
+        out[name + '/preds'] = preds.detach().numpy(); out[name + '/loss'] = np.array(loss.item())
+        out[name + '/dXr'] = Xr.grad.numpy().copy(); out[name + '/dXi'] = Xi.grad.numpy().copy()
+        for k, v in net.state_dict().items():
+            out[name + '/state/' + k] = v.numpy().copy()
+        for k, p in net.named_parameters():
+            out[name + '/grad/' + k] = p.grad.numpy().copy()
+        # ---- link prediction (ChebNet_Edge) ----
+        name = 'edge_' + tag; names.append(name)
+        torch.manual_seed(300 + K + layer)
+        net = ChebNet_Edge(cin, Lr, Li, num_filter=F, K=K, label_dim=3, activation=act, layer=layer, dropout=0.0)
+        for m in net.Chebs:
+            if hasattr(m, 'bias'):
+                with torch.no_grad():
+                    m.bias.uniform_(-0.3, 0.3)
+        Xr = X.clone().requires_grad_(True); Xi = X.clone().requires_grad_(True)
+        pairs = torch.from_numpy(rng.integers(0, 245, (300, 2)))
+        yl = torch.from_numpy(rng.integers(0, 3, 300))
+        o = net(Xr, Xi, pairs)
+        loss = torch.nn.functional.nll_loss(o, yl)
+        loss.backward()
+        out[name + '/params'] = np.array([K, layer, float(act), F, q, cin], np.float64)
+        out[name + '/X'] = X.numpy(); out[name + '/pairs'] = pairs.numpy(); out[name + '/y'] = yl.numpy()
+        out[name + '/out'] = o.detach().numpy(); out[name + '/loss'] = np.array(loss.item())
+        out[name + '/dXr'] = Xr.grad.numpy().copy(); out[name + '/dXi'] = Xi.grad.numpy().copy()
+        for k, v in net.state_dict().items():
+            out[name + '/state/' + k] = v.numpy().copy()
+        for k, p in net.named_parameters():
+            out[name + '/grad/' + k] = p.grad.numpy().copy()
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'net_cases.npz'), **out)
+    print('net_cases:', names)
+
+
+def citeseer_case(ref_h, ref_c, ChebNet_Edge):
+    """Config-3 shaped step: CiteSeer graph, K=2, q=0.1, F=16, quirky degree features, fwd+bwd."""
+    from utils.edge_data import in_out_degree
+    c = np.load(os.path.join(REF, 'dataset/data/tmp/citeseer_npz/citeseer_npz.npz'), allow_pickle=False)
+    A = sp.csr_matrix((c['adj_data'], c['adj_indices'], c['adj_indptr']), shape=tuple(c['adj_shape'])).tocoo()
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    keep = rng.random(A.nnz) < 0.85                       # observed graph of a link split
+    row = A.row[keep].astype(np.int64); col = A.col[keep].astype(np.int64)
+    edges = torch.from_numpy(np.vstack([row, col]))
+    L = ref_c(ref_h(edges[0], edges[1], n, 0.1, True, True, 2.0, False, None), 2)
+    Lr, Li = to_coo_lists(L)
+    X = in_out_degree(edges, n)                            # called with [2,E] as the driver does
+    torch.manual_seed(33)
+    net = ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=2, label_dim=3, activation=True, layer=2, dropout=0.0)
+    pairs = torch.from_numpy(rng.integers(0, n, (700, 2)))
+    yl = torch.from_numpy(rng.integers(0, 3, 700))
+    o = net(X.clone(), X.clone(), pairs)
+    loss = torch.nn.functional.nll_loss(o, yl)
+    loss.backward()
+    out = dict(row=row, col=col, n=np.array(n), X=X.numpy(), pairs=pairs.numpy(), y=yl.numpy(),
+               out=o.detach().numpy(), loss=np.array(loss.item()))
+    Lc = L[1].tocsr(); Lc.sort_indices()
+    out['indptr'] = Lc.indptr.astype(np.int32); out['indices'] = Lc.indices.astype(np.int32)
+    out['data'] = Lc.data.astype(np.complex64)
+    for k, v in net.state_dict().items():
+        out['state/' + k] = v.numpy().copy()
+    for k, p in net.named_parameters():
+        out['grad/' + k] = p.grad.numpy().copy()
+    # the degree-feature quirk on a second, tiny input
+    e2 = torch.tensor([[0, 1, 2, 3, 1], [2, 2, 0, 1, 3]])
+    out['iod_small_in'] = e2.numpy(); out['iod_small_out'] = in_out_degree(e2, 5).numpy()
+    np.savez_compressed(os.path.join(HERE, 'citeseer_link_case.npz'), **out)
+    print('citeseer_link_case: n=%d E_obs=%d nnz=%d' % (n, len(row), Lc.nnz))
+
+
+def telegram_cache():
+    """The Laplacian caches the reference ships (written by src/utils/preprocess.py:185-191),
+    read with the inert opcode walker (nothing in the files is executed) and re-stored as
+    plain arrays: T_1 of every cache and T_2 of the K=2 ones."""
+    sys.path.insert(0, os.path.join(HERE, '..', '..'))
+    from tools.inert_pickle import read_sparse_list
+    import glob
+    out = {}
+    names = []
+    for p in sorted(glob.glob(os.path.join(REF, 'dataset/data/tmp/telegram/telegram/data*_sparse.pk'))):
+        tag = os.path.basename(p)[len('data'):-len('_sparse.pk')]          # '<q>_<K>'
+        L = read_sparse_list(p)
+        assert L[0]['__class__'].endswith('coo_matrix') and np.array_equal(L[0]['row'], np.arange(245))
+        names.append(tag)
+        for k in range(1, len(L)):
+            assert L[k]['__class__'].endswith('csr_matrix')
+            out['%s/T%d/indptr' % (tag, k)] = L[k]['indptr']
+            out['%s/T%d/indices' % (tag, k)] = L[k]['indices']
+            out['%s/T%d/data' % (tag, k)] = L[k]['data']
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'telegram_cache.npz'), **out)
+    print('telegram_cache:', names)
+
+
+if __name__ == '__main__':
+    telegram_cache()
+    ref_h, ref_c, ChebConv, ChebNet, ChebNet_Edge = _import_reference()
+    lap_cases(ref_h)
+    cheb_cases(ref_h, ref_c)
+    conv_cases(ref_h, ref_c, ChebConv)
+    net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge)
+    citeseer_case(ref_h, ref_c, ChebNet_Edge)
