@@ -1,0 +1,132 @@
+/* magnet_hip.h — C ABI of libmagnet_hip.so, the MI355X (gfx950) implementation of
+ * MagNet's complex magnetic-Laplacian propagation.
+ *
+ * The reference (Qin87/magnet) has no FFI layer: its hot path is Python calling
+ * scipy and torch.sparse.  Each entry point below names the reference code it
+ * replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - the caller owns all memory; the library allocates nothing;
+ *   - return value: 0 = ok, <0 = error (mh_last_error() gives the text for the
+ *     calling thread); no exception crosses this boundary;
+ *   - calls are asynchronous on `stream` unless stated otherwise.
+ *
+ * Complex feature matrices use the ROW-PLANAR layout: a matrix of N rows and F
+ * complex columns is float32 [N][2][F] — for each node the F real parts, then the
+ * F imaginary parts.  Entry points take a row stride `ld` (floats between
+ * consecutive rows) and `im` (floats from a row's real block to its imaginary
+ * block), so a block of a wider buffer can be addressed in place.
+ */
+#ifndef MAGNET_HIP_H
+#define MAGNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_ARG (-1)        /* bad argument (null pointer, size, alignment) */
+#define MH_ERR_HIP (-2)        /* a HIP runtime call failed */
+#define MH_ERR_INDEX (-3)      /* an edge endpoint is outside [0, n_nodes) */
+#define MH_ERR_WORKSPACE (-4)  /* workspace too small */
+#define MH_ERR_RANGE (-5)      /* problem too large for int32 CSR indices */
+
+int mh_version(void);
+const char* mh_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Magnetic Laplacian builder.
+ * Replaces hermitian_decomp_sparse(row, col, size, q, norm=True, laplacian=True,
+ * max_eigen, gcn_appr, edge_weight)   — src/utils/hermitian.py:136-168 — called
+ * from src/utils/preprocess.py:177-181 and :230.
+ *
+ * Output is the reference's CSR: int32 row_ptr[n+1], int32 col_idx[nnz] sorted
+ * inside each row, complex64 val[nnz] (as float2: re, im); support = pairs with
+ * w_ij != w_ji, no diagonal when max_eigen == 2.
+ *
+ * Two phases because nnz is data dependent:
+ *   mh_lap_workspace_bytes  -> size of the scratch buffer for (n_edges, n_nodes)
+ *   mh_lap_build_count      -> sorts the edge records, writes row_ptr and the
+ *                              per-node d^-1/2, returns nnz (SYNCHRONISES stream)
+ *   mh_lap_build_fill       -> writes col_idx and val from the same workspace
+ * The workspace must stay untouched between count and fill.
+ * `row`/`col` are int64 when idx64 != 0, else int32.  `weight` may be NULL
+ * (every edge has weight 1).  dinv (float[n_nodes], may be NULL in fill only if
+ * not wanted back) receives d_i^-1/2.
+ */
+size_t mh_lap_workspace_bytes(int64_t n_edges, int32_t n_nodes, int weighted, int gcn_appr);
+
+int mh_lap_build_count(const void* row, const void* col, int idx64, const float* weight,
+                       int64_t n_edges, int32_t n_nodes, float max_eigen, int gcn_appr,
+                       void* workspace, size_t workspace_bytes,
+                       int32_t* row_ptr, int64_t* nnz_host, void* stream);
+
+int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, float q, float max_eigen, int weighted,
+                      int gcn_appr, void* workspace, size_t workspace_bytes,
+                      int64_t nnz /* as returned by count */, int32_t* col_idx, float* val /* [nnz][2] */,
+                      float* dinv_out /* [n_nodes] or NULL */, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused complex CSR SpMM, one Chebyshev order.
+ * Replaces the four torch.spmm of process()  — src/layer/sparse_magnet.py:9-17 —
+ * (L_re X_re - L_im X_im, L_im X_re + L_re X_im) and the axpy of the recursion
+ * T_k = 2 L T_{k-1} - T_{k-2}  — src/utils/hermitian.py:132 — applied to features:
+ *
+ *     Y = alpha * (L X) + beta1 * Z1 + beta2 * Z2   [+ bias on both parts][complex ReLU]
+ *
+ * L: CSR (row_ptr[n_rows+1], col_idx, val) ; column indices address rows of X.
+ * X, Y, Z1, Z2: row-planar complex float32 with their own (ld, im).  Z1/Z2 may be
+ * NULL.  bias: float[F] or NULL (src/layer/sparse_magnet.py:72).  relu != 0
+ * applies mask = (Re >= 0) to both parts (src/layer/sparse_magnet.py:79-81); if
+ * mask_out != NULL the mask is stored as uint8 [n_rows][F] for the backward pass.
+ * Y may alias Z1 or Z2 (same ld/im) but not X.  All bases 16-byte aligned and
+ * ld, im multiples of 4 when F % 4 == 0 (vector path); any F otherwise.
+ * Deterministic: no atomics, fixed summation order.
+ */
+int mh_cspmm(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n_rows,
+             const float* X, int64_t ldx, int64_t imx,
+             float* Y, int64_t ldy, int64_t imy,
+             float alpha,
+             const float* Z1, int64_t ldz1, int64_t imz1, float beta1,
+             const float* Z2, int64_t ldz2, int64_t imz2, float beta2,
+             const float* bias, int relu, uint8_t* mask_out,
+             int32_t F, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Layout and activation helpers around the SpMM.
+ */
+
+/* (real[N][F], imag[N][F]) with row strides ld_re/ld_im  ->  row-planar out.
+ * Replaces nothing in the reference (it keeps two tensors); it is the entry into
+ * the layout the SpMM streams.  torch.cat((real, imag), -1) of
+ * src/layer/sparse_magnet.py:121 is the same memory as the packed result. */
+int mh_pack(const float* re, int64_t ld_re, const float* im_, int64_t ld_im,
+            float* out, int64_t ld, int64_t im, int64_t n_rows, int32_t F, void* stream);
+
+/* In place on row-planar Y: add bias[F] to both parts (NULL = none), then the
+ * complex ReLU when relu != 0, storing the mask when mask_out != NULL.
+ * src/layer/sparse_magnet.py:72 and :79-81. */
+int mh_bias_relu(float* Y, int64_t ld, int64_t im, const float* bias, int relu,
+                 uint8_t* mask_out, int64_t n_rows, int32_t F, void* stream);
+
+/* Backward of the complex ReLU: G *= mask on both parts (autograd of
+ * src/layer/sparse_magnet.py:80-81; the mask itself carries no gradient). */
+int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask,
+                int64_t n_rows, int32_t F, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Synthetic power-law digraph (bench / scale tests).  Edge e (0-based, global
+ * id first_edge + e) gets src = floor(N u1^2), dst = floor(N u2^2) with u from
+ * Philox4x32-10, counter = edge id, key = seed.  Stands in for the reference's
+ * host-side generators (src/utils/generate_cyclic.py:79-143) at graph scale.
+ */
+int mh_powerlaw_edges(int32_t n_nodes, int64_t n_edges, uint64_t seed, int64_t first_edge,
+                      int32_t* src, int32_t* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGNET_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libmagnet_hip.so (declared in include/magnet_hip.h).
+
+The library is the product path: if it is missing the import fails loudly; there
+is no CPU fallback.  Device pointers come from torch tensors (torch is only the
+allocator / stream owner here).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmagnet_hip.so')
+
+
+class MagnetHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libmagnet_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C magnet_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    i32, i64, u64, f32, vp, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p, C.c_size_t
+    lib.mh_version.restype = C.c_int
+    lib.mh_last_error.restype = C.c_char_p
+    lib.mh_lap_workspace_bytes.restype = sz
+    lib.mh_lap_workspace_bytes.argtypes = [i64, i32, C.c_int, C.c_int]
+    lib.mh_lap_build_count.restype = C.c_int
+    lib.mh_lap_build_count.argtypes = [vp, vp, C.c_int, vp, i64, i32, f32, C.c_int, vp, sz, vp,
+                                       C.POINTER(i64), vp]
+    lib.mh_lap_build_fill.restype = C.c_int
+    lib.mh_lap_build_fill.argtypes = [i64, i32, f32, f32, C.c_int, C.c_int, vp, sz, i64, vp, vp, vp, vp]
+    lib.mh_cspmm.restype = C.c_int
+    lib.mh_cspmm.argtypes = [vp, vp, vp, i32,
+                             vp, i64, i64,
+                             vp, i64, i64, f32,
+                             vp, i64, i64, f32,
+                             vp, i64, i64, f32,
+                             vp, C.c_int, vp, i32, vp]
+    lib.mh_pack.restype = C.c_int
+    lib.mh_pack.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i32, vp]
+    lib.mh_bias_relu.restype = C.c_int
+    lib.mh_bias_relu.argtypes = [vp, i64, i64, vp, C.c_int, vp, i64, i32, vp]
+    lib.mh_relu_bwd.restype = C.c_int
+    lib.mh_relu_bwd.argtypes = [vp, i64, i64, vp, i64, i32, vp]
+    lib.mh_powerlaw_edges.restype = C.c_int
+    lib.mh_powerlaw_edges.argtypes = [i32, i64, u64, i64, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+EXPORTS = ['mh_version', 'mh_last_error', 'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
+           'mh_cspmm', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
+
+
+def check(rc):
+    if rc != 0:
+        raise MagnetHipError('libmagnet_hip error %d: %s' % (rc, lib.mh_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MagnetHipError('magnet_amd runs on the GPU only: got a %s tensor' % t.device)

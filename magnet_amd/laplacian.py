@@ -1,0 +1,214 @@
+"""Device-resident magnetic Laplacian (complex CSR) and the calls into libmagnet_hip.so
+that build it and apply it.
+
+`build_magnetic_laplacian` is the GPU counterpart of hermitian_decomp_sparse
+(reference src/utils/hermitian.py:136-168); `MagneticLaplacian.spmm` is one order of the
+propagation (the four torch.spmm of reference src/layer/sparse_magnet.py:9-17 in one pass).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr, require_cuda, MagnetHipError
+
+
+def _packed_strides(t, what):
+    """(ld, im) of a row-planar complex tensor [N, 2, F] (last dim contiguous)."""
+    if t.dim() != 3 or t.size(1) != 2 or t.dtype != torch.float32:
+        raise MagnetHipError('%s must be float32 [N, 2, F], got %s %s' % (what, t.dtype, tuple(t.shape)))
+    if t.size(2) > 1 and t.stride(2) != 1:
+        raise MagnetHipError('%s: feature dimension must be contiguous' % what)
+    return t.stride(0), t.stride(1)
+
+
+def pack_complex(real, imag, out=None):
+    """(real [N,F], imag [N,F]) -> row-planar float32 [N, 2, F] on the GPU (mh_pack)."""
+    require_cuda(real, imag)
+    if real.shape != imag.shape or real.dim() != 2:
+        raise MagnetHipError('real/imag must be [N, F] of equal shape, got %s and %s' % (tuple(real.shape), tuple(imag.shape)))
+    real = real.float(); imag = imag.float()
+    if real.size(1) > 1 and real.stride(1) != 1:
+        real = real.contiguous()
+    if imag.size(1) > 1 and imag.stride(1) != 1:
+        imag = imag.contiguous()
+    n, f = real.shape
+    if out is None:
+        out = torch.empty((n, 2, f), dtype=torch.float32, device=real.device)
+    ld, im = _packed_strides(out, 'out')
+    if n:
+        check(_lib.lib.mh_pack(ptr(real), real.stride(0), ptr(imag), imag.stride(0), ptr(out), ld, im, n, f,
+                               stream_ptr(real.device)))
+    return out
+
+
+class MagneticLaplacian:
+    """Complex CSR on the device: row_ptr int32 [n_rows+1], col_idx int32 [nnz],
+    val float32 [nnz, 2] (re, im).  `n_cols` rows of the operand are addressed by col_idx."""
+
+    def __init__(self, row_ptr, col_idx, val, n_cols, q=None, dinv=None):
+        require_cuda(row_ptr, col_idx, val)
+        assert row_ptr.dtype == torch.int32 and col_idx.dtype == torch.int32 and val.dtype == torch.float32
+        self.row_ptr, self.col_idx, self.val = row_ptr.contiguous(), col_idx.contiguous(), val.contiguous()
+        self.n_rows = row_ptr.numel() - 1
+        self.n_cols = int(n_cols)
+        self.nnz = col_idx.numel()
+        self.q = q
+        self.dinv = dinv
+        self._adjoint = None
+
+    @property
+    def device(self):
+        return self.row_ptr.device
+
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_cols)
+
+    # -- one propagation order ------------------------------------------------
+    def spmm(self, X, out=None, alpha=1.0, z1=None, beta1=0.0, z2=None, beta2=0.0, bias=None, relu=False,
+             mask=None):
+        """out = alpha * (L X) + beta1 * z1 + beta2 * z2 [+ bias][complex ReLU]; all row-planar [*, 2, F]."""
+        require_cuda(X, out, z1, z2, bias, mask)
+        ldx, imx = _packed_strides(X, 'X')
+        if X.size(0) != self.n_cols:
+            raise MagnetHipError('X has %d rows, the Laplacian has %d columns' % (X.size(0), self.n_cols))
+        f = X.size(2)
+        if out is None:
+            out = torch.empty((self.n_rows, 2, f), dtype=torch.float32, device=X.device)
+        ldy, imy = _packed_strides(out, 'out')
+        if out.size(0) != self.n_rows or out.size(2) != f:
+            raise MagnetHipError('out has shape %s, expected (%d, 2, %d)' % (tuple(out.shape), self.n_rows, f))
+        zargs = []
+        for z, b, name in ((z1, beta1, 'z1'), (z2, beta2, 'z2')):
+            if z is None:
+                zargs += [None, 0, 0, 0.0]
+            else:
+                ldz, imz = _packed_strides(z, name)
+                if z.size(0) != self.n_rows or z.size(2) != f:
+                    raise MagnetHipError('%s has shape %s, expected (%d, 2, %d)' % (name, tuple(z.shape), self.n_rows, f))
+                zargs += [ptr(z), ldz, imz, float(b)]
+        if bias is not None:
+            bias = bias.reshape(-1).float().contiguous()
+            if bias.numel() != f:
+                raise MagnetHipError('bias has %d entries, expected %d' % (bias.numel(), f))
+        if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != self.n_rows * f or not mask.is_contiguous()):
+            raise MagnetHipError('mask must be contiguous uint8 [n_rows, F]')
+        check(_lib.lib.mh_cspmm(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), self.n_rows,
+                                ptr(X), ldx, imx, ptr(out), ldy, imy, float(alpha), *zargs,
+                                ptr(bias), int(bool(relu)), ptr(mask), f, stream_ptr(X.device)))
+        return out
+
+    # -- conversions ----------------------------------------------------------
+    def to_scipy(self):
+        import scipy.sparse as sp
+        val = self.val.cpu().numpy()
+        data = (val[:, 0] + 1j * val[:, 1]).astype(np.complex64) if self.nnz else np.zeros(0, np.complex64)
+        return sp.csr_matrix((data, self.col_idx.cpu().numpy(), self.row_ptr.cpu().numpy()),
+                             shape=(self.n_rows, self.n_cols))
+
+    @staticmethod
+    def from_scipy(mx, device='cuda'):
+        mx = mx.tocsr()
+        mx.sort_indices()
+        data = np.asarray(mx.data).astype(np.complex64)
+        val = torch.from_numpy(np.stack([data.real, data.imag], axis=1).astype(np.float32))
+        return MagneticLaplacian(torch.from_numpy(mx.indptr.astype(np.int32)).to(device),
+                                 torch.from_numpy(mx.indices.astype(np.int32)).to(device),
+                                 val.to(device), mx.shape[1])
+
+    @staticmethod
+    def from_coo_pair(L_real, L_imag):
+        """Complex CSR from the reference's two real COO tensors (src/sparse_Magnet.py:108-112)."""
+        L_real = L_real.coalesce() if L_real.is_sparse else L_real.to_sparse().coalesce()
+        L_imag = L_imag.coalesce() if L_imag.is_sparse else L_imag.to_sparse().coalesce()
+        require_cuda(L_real.values(), L_imag.values())
+        n_rows, n_cols = L_real.shape
+        ir, ii = L_real.indices(), L_imag.indices()
+        key = torch.cat([ir[0] * n_cols + ir[1], ii[0] * n_cols + ii[1]])
+        uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+        val = torch.zeros((uniq.numel(), 2), dtype=torch.float32, device=key.device)
+        nr = ir.size(1)
+        val[:, 0].index_add_(0, inv[:nr], L_real.values().float())
+        val[:, 1].index_add_(0, inv[nr:], L_imag.values().float())
+        rows = torch.div(uniq, n_cols, rounding_mode='floor')
+        cols = (uniq - rows * n_cols).to(torch.int32)
+        counts = torch.bincount(rows, minlength=n_rows)
+        row_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=key.device)
+        row_ptr[1:] = torch.cumsum(counts, 0)
+        return MagneticLaplacian(row_ptr.to(torch.int32), cols, val, n_cols)
+
+    def adjoint(self):
+        """Conjugate transpose as its own CSR (used by the backward pass of matrices that are not Hermitian)."""
+        if self._adjoint is None:
+            counts = (self.row_ptr[1:] - self.row_ptr[:-1]).long()
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), counts)
+            key = self.col_idx.long() * self.n_rows + rows
+            order = torch.argsort(key, stable=True)
+            new_rows = self.col_idx.long()[order]
+            val = self.val[order].clone()
+            val[:, 1].neg_()
+            rp = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=self.device)
+            rp[1:] = torch.cumsum(torch.bincount(new_rows, minlength=self.n_cols), 0)
+            self._adjoint = MagneticLaplacian(rp.to(torch.int32), rows[order].to(torch.int32), val, self.n_rows)
+            self._adjoint._adjoint = self
+        return self._adjoint
+
+
+def build_magnetic_laplacian(row, col, size, q=0.25, max_eigen=2.0, gcn_appr=False, edge_weight=None, device=None):
+    """GPU build of the normalised, rescaled magnetic Laplacian (hermitian_decomp_sparse with
+    norm=True, laplacian=True; reference src/utils/hermitian.py:136-168).  `row`/`col` may be
+    torch tensors (any device), numpy arrays or lists."""
+    if device is None:
+        device = row.device if isinstance(row, torch.Tensor) and row.is_cuda else torch.device('cuda')
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise MagnetHipError('the Laplacian builder runs on the GPU only')
+
+    def as_index(a):
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+        t = t.reshape(-1)
+        if t.dtype not in (torch.int32, torch.int64):
+            t = t.long()
+        return t.to(device).contiguous()
+
+    row_t, col_t = as_index(row), as_index(col)
+    if col_t.dtype != row_t.dtype:
+        row_t, col_t = row_t.long(), col_t.long()
+    if row_t.numel() != col_t.numel():
+        raise MagnetHipError('row and col differ in length')
+    w_t = None
+    if edge_weight is not None:
+        w_t = edge_weight if isinstance(edge_weight, torch.Tensor) else torch.as_tensor(np.asarray(edge_weight))
+        w_t = w_t.reshape(-1).to(torch.float32).to(device).contiguous()
+        if w_t.numel() != row_t.numel():
+            raise MagnetHipError('edge_weight and row differ in length')
+    n_edges, n = row_t.numel(), int(size)
+    lib = _lib.lib
+    with torch.cuda.device(device):
+        ws_bytes = lib.mh_lap_workspace_bytes(n_edges, n, int(w_t is not None), int(bool(gcn_appr)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        row_ptr = torch.empty(n + 1, dtype=torch.int32, device=device)
+        nnz = C.c_int64(0)
+        s = stream_ptr(device)
+        check(lib.mh_lap_build_count(ptr(row_t), ptr(col_t), int(row_t.dtype == torch.int64), ptr(w_t), n_edges, n,
+                                     float(max_eigen), int(bool(gcn_appr)), ptr(ws), ws_bytes, ptr(row_ptr),
+                                     C.byref(nnz), s))
+        col_idx = torch.empty(nnz.value, dtype=torch.int32, device=device)
+        val = torch.empty((nnz.value, 2), dtype=torch.float32, device=device)
+        dinv = torch.empty(n, dtype=torch.float32, device=device)
+        check(lib.mh_lap_build_fill(n_edges, n, float(q), float(max_eigen), int(w_t is not None), int(bool(gcn_appr)),
+                                    ptr(ws), ws_bytes, nnz.value, ptr(col_idx), ptr(val), ptr(dinv), s))
+        ws.record_stream(torch.cuda.current_stream(device))
+    return MagneticLaplacian(row_ptr, col_idx, val, n, q=q, dinv=dinv)
+
+
+def powerlaw_edges(n_nodes, n_edges, seed, first_edge=0, device='cuda'):
+    """Synthetic power-law digraph on the device (mh_powerlaw_edges): int32 src, dst."""
+    src = torch.empty(n_edges, dtype=torch.int32, device=device)
+    dst = torch.empty(n_edges, dtype=torch.int32, device=device)
+    check(_lib.lib.mh_powerlaw_edges(int(n_nodes), int(n_edges), int(seed), int(first_edge), ptr(src), ptr(dst),
+                                     stream_ptr(torch.device(device))))
+    return src, dst

@@ -1,0 +1,456 @@
+"""Drop-in for the reference's layer/sparse_magnet.py on MI355X.
+
+Same names, constructor arguments, forward signatures and state_dict keys as
+reference src/layer/sparse_magnet.py:8-165:
+
+    process(mul_L_real, mul_L_imag, weight, X_real, X_imag) -> [2, N, C_out]
+    ChebConv(in_c, out_c, K, L_norm_real, L_norm_imag, bias=True).forward((X_real, X_imag))
+    complex_relu_layer().forward(real, img=None)
+    ChebNet(in_c, L_norm_real, L_norm_imag, num_filter, K, label_dim, activation, layer, dropout)
+        .forward(real, imag)                      -> [1, label_dim, N]
+    ChebNet_Edge(... same ...).forward(real, imag, index) -> [M, label_dim]
+    MagNetConv(in_c, out_c, K, q).forward(real, imag, edge_index, edge_weight=None)
+
+`L_norm_real` / `L_norm_imag` may be
+  * a ChebBasis (utils.hermitian.cheb_poly_sparse) or a MagneticLaplacian: the layer runs the
+    feature-side recursion  Z_k = 2 L Z_{k-1} - Z_{k-2}  with the fused complex SpMM and never
+    forms T_k (L_norm_imag is then ignored and may be None);
+  * the reference's two lists of K+1 torch sparse tensors (src/sparse_Magnet.py:108-112): every
+    T_k is converted once to a complex CSR and applied with the same kernel
+    (sum_k (T_k X) W_k, exactly the reference's formula for arbitrary lists).
+
+Between layers features stay in the row-planar layout [N, 2, F] (one tensor holding the real
+and the imaginary block of every node); the (real, imag) tensors handed back are views of it.
+All sparse work, bias and the complex ReLU run in libmagnet_hip.so; the dense per-order weight
+GEMM is torch.mm (hipBLASLt).  GPU only.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr, MagnetHipError
+from ..laplacian import MagneticLaplacian, build_magnetic_laplacian, pack_complex, _packed_strides
+from ..utils.hermitian import ChebBasis
+
+
+# ----------------------------------------------------------------------------
+# packed (row-planar) features
+# ----------------------------------------------------------------------------
+class _PackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real, imag):
+        return pack_complex(real, imag)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, 0, :], g[:, 1, :]
+
+
+def _as_packed(real, imag):
+    """Row-planar tensor of a (real, imag) pair; free when the pair are views handed out by a layer here."""
+    p = getattr(real, '_mh_packed', None)
+    if p is not None and getattr(imag, '_mh_packed', None) is p:
+        return p
+    if not real.is_cuda:
+        raise MagnetHipError('magnet_amd layers run on the GPU only (got %s tensors)' % real.device)
+    return _PackFn.apply(real, imag)
+
+
+def _views(p):
+    real, imag = p[:, 0, :], p[:, 1, :]
+    real._mh_packed = p
+    imag._mh_packed = p
+    return real, imag
+
+
+def _rows2(p):
+    """[N, 2, F] -> [2N, F] view for the weight GEMM (real and imaginary rows share the real weight)."""
+    return p.reshape(p.size(0) * 2, p.size(2))
+
+
+def _bias_relu_(p, bias, relu):
+    """In place: + bias on both parts, complex ReLU; returns the uint8 mask (or None)."""
+    n, _, f = p.shape
+    mask = torch.empty((n, f), dtype=torch.uint8, device=p.device) if relu else None
+    if bias is None and not relu:
+        return None
+    ld, im = _packed_strides(p, 'Y')
+    b = None if bias is None else bias.detach().reshape(-1).float().contiguous()
+    check(_lib.lib.mh_bias_relu(ptr(p), ld, im, ptr(b), int(relu), ptr(mask), n, f, stream_ptr(p.device)))
+    return mask
+
+
+def _relu_bwd_(g, mask):
+    n, _, f = g.shape
+    ld, im = _packed_strides(g, 'G')
+    check(_lib.lib.mh_relu_bwd(ptr(g), ld, im, ptr(mask), n, f, stream_ptr(g.device)))
+    return g
+
+
+# ----------------------------------------------------------------------------
+# Chebyshev propagation with the fused SpMM
+# ----------------------------------------------------------------------------
+def _cheb_terms(lap, x0, n_terms):
+    """[T_0 x, T_1 x, ..., T_{n-1} x] by the three-term recursion (K SpMMs)."""
+    zs = [x0]
+    if n_terms > 1:
+        zs.append(lap.spmm(x0))
+    for k in range(2, n_terms):
+        zs.append(lap.spmm(zs[k - 1], alpha=2.0, z1=zs[k - 2], beta1=-1.0))
+    return zs
+
+
+def _clenshaw(lap, ys, bias=None, relu=False):
+    """sum_k T_k(L) ys[k] by Clenshaw's recurrence (K SpMMs); bias / complex ReLU fused into the
+    last SpMM.  Returns (result, mask)."""
+    n_terms = len(ys)
+    n, _, f = ys[0].shape
+    mask = torch.empty((n, f), dtype=torch.uint8, device=ys[0].device) if relu else None
+    if n_terms == 1:
+        out = ys[0].clone(memory_format=torch.contiguous_format)
+        m = _bias_relu_(out, bias, relu)
+        return out, m
+    b2 = None                     # b_{k+2}
+    b1 = ys[n_terms - 1]          # b_{k+1}, starts as b_K = y_K
+    for k in range(n_terms - 2, 0, -1):
+        nb = lap.spmm(b1, alpha=2.0, z1=ys[k], beta1=1.0, z2=b2, beta2=-1.0)
+        b2, b1 = b1, nb
+    out = lap.spmm(b1, alpha=1.0, z1=ys[0], beta1=1.0, z2=b2, beta2=-1.0, bias=bias, relu=relu, mask=mask)
+    return out, mask
+
+
+class _ChebConvFn(torch.autograd.Function):
+    """out = sum_k T_k(L) X W_k + bias (+ complex ReLU), L Hermitian.
+
+    SpMM-first (C_in <= C_out): Z_k = T_k X by recursion, then one GEMM per order.
+    GEMM-first (C_out < C_in):  Y_k = X W_k in one GEMM, then Clenshaw on the narrower Y.
+    Backward uses T_k^H = T_k: dX = sum_k T_k (G W_k^T), dW_k = (T_k X)^T G = X^T (T_k G)."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, bias, lap, relu):
+        xp = xp.contiguous()
+        n, _, cin = xp.shape
+        k1, _, cout = weight.shape
+        w = weight.detach()
+        gemm_first = cout < cin
+        if gemm_first:
+            ycat = torch.mm(_rows2(xp), w.permute(1, 0, 2).reshape(cin, k1 * cout)).view(n, 2, k1, cout)
+            out, mask = _clenshaw(lap, [ycat[:, :, k, :] for k in range(k1)], None if bias is None else bias.detach(), relu)
+            saved_z = None
+        else:
+            zs = _cheb_terms(lap, xp, k1)
+            o2 = torch.mm(_rows2(zs[0]), w[0])
+            for k in range(1, k1):
+                o2.addmm_(_rows2(zs[k]), w[k])
+            out = o2.view(n, 2, cout)
+            mask = _bias_relu_(out, None if bias is None else bias.detach(), relu)
+            saved_z = zs
+        ctx.lap, ctx.relu, ctx.gemm_first, ctx.has_bias = lap, relu, gemm_first, bias is not None
+        ctx.mask = mask
+        ctx.zs = saved_z
+        ctx.save_for_backward(xp, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, weight = ctx.saved_tensors
+        lap = ctx.lap
+        n, _, cin = xp.shape
+        k1, _, cout = weight.shape
+        w = weight.detach()
+        g = g.contiguous()
+        if ctx.relu:
+            g = _relu_bwd_(g.clone(), ctx.mask)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_b:
+            db = g.sum(dim=(0, 1)).view(1, cout)          # the same real bias sits on both parts
+        g2 = _rows2(g)
+        if ctx.gemm_first:
+            ds = _cheb_terms(lap, g, k1) if (need_w or need_x) else None     # T_k G
+            if need_w:
+                dw = torch.stack([torch.mm(_rows2(xp).t(), _rows2(d)) for d in ds])
+            if need_x:
+                dx2 = torch.mm(_rows2(ds[0]), w[0].t())
+                for k in range(1, k1):
+                    dx2.addmm_(_rows2(ds[k]), w[k].t())
+                dx = dx2.view(n, 2, cin)
+        else:
+            if need_w:
+                dw = torch.stack([torch.mm(_rows2(z).t(), g2) for z in ctx.zs])
+            if need_x:
+                hcat = torch.mm(g2, w.permute(2, 0, 1).reshape(cout, k1 * cin)).view(n, 2, k1, cin)
+                dx, _ = _clenshaw(lap, [hcat[:, :, k, :] for k in range(k1)])
+        return dx, dw, db, None, None
+
+
+class _ListConvFn(torch.autograd.Function):
+    """out = sum_k (T_k X) W_k + bias (+ complex ReLU) for an arbitrary list of complex CSR matrices
+    (the reference's calling convention).  Backward applies the conjugate transposes."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, bias, laps, relu):
+        xp = xp.contiguous()
+        n, _, cin = xp.shape
+        k1, _, cout = weight.shape
+        w = weight.detach()
+        zs = [lap.spmm(xp) for lap in laps]
+        o2 = torch.mm(_rows2(zs[0]), w[0])
+        for k in range(1, len(laps)):
+            o2.addmm_(_rows2(zs[k]), w[k])
+        out = o2.view(zs[0].size(0), 2, cout)
+        ctx.mask = _bias_relu_(out, None if bias is None else bias.detach(), relu)
+        ctx.laps, ctx.relu, ctx.zs, ctx.has_bias = laps, relu, zs, bias is not None
+        ctx.save_for_backward(xp, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, weight = ctx.saved_tensors
+        n, _, cin = xp.shape
+        k1, _, cout = weight.shape
+        w = weight.detach()
+        g = g.contiguous()
+        if ctx.relu:
+            g = _relu_bwd_(g.clone(), ctx.mask)
+        dx = dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(dim=(0, 1)).view(1, cout)
+        g2 = _rows2(g)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            for k, z in enumerate(ctx.zs):
+                dw[k] = torch.mm(_rows2(z).t(), g2)
+        if ctx.needs_input_grad[0]:
+            for k, lap in enumerate(ctx.laps):
+                h = torch.mm(g2, w[k].t()).view(g.size(0), 2, cin)
+                dx = lap.adjoint().spmm(h, z1=dx, beta1=1.0 if dx is not None else 0.0)
+        return dx, dw, db, None, None
+
+
+class _ComplexReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p):
+        out = p.clone()
+        ctx.mask = _bias_relu_(out, None, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _relu_bwd_(g.contiguous().clone(), ctx.mask)
+
+
+# ----------------------------------------------------------------------------
+# Laplacian argument handling
+# ----------------------------------------------------------------------------
+_COO_CACHE = {}
+
+
+def _lap_from_pair(l_real, l_imag):
+    """Complex CSR of one (real, imag) pair of torch sparse tensors, cached per tensor pair."""
+    key = (id(l_real), id(l_imag))
+    hit = _COO_CACHE.get(key)
+    if hit is not None and hit[0] is l_real and hit[1] is l_imag:
+        return hit[2]
+    lap = MagneticLaplacian.from_coo_pair(l_real, l_imag)
+    if len(_COO_CACHE) > 64:
+        _COO_CACHE.clear()
+    _COO_CACHE[key] = (l_real, l_imag, lap)
+    return lap
+
+
+def _resolve_laplacian(L_norm_real, L_norm_imag):
+    """-> ('cheb', MagneticLaplacian, n_terms or None) or ('list', [MagneticLaplacian...], n_terms)"""
+    if isinstance(L_norm_real, ChebBasis):
+        return 'cheb', L_norm_real.laplacian, len(L_norm_real)
+    if isinstance(L_norm_real, MagneticLaplacian):
+        return 'cheb', L_norm_real, None
+    if isinstance(L_norm_real, (list, tuple)) and all(isinstance(l, MagneticLaplacian) for l in L_norm_real):
+        return 'list', list(L_norm_real), len(L_norm_real)
+    if isinstance(L_norm_real, (list, tuple)) and isinstance(L_norm_imag, (list, tuple)):
+        if len(L_norm_real) != len(L_norm_imag):
+            raise MagnetHipError('L_norm_real and L_norm_imag differ in length')
+        return 'list', None, len(L_norm_real)          # converted lazily (tensors may still move to the GPU)
+    raise MagnetHipError('unsupported Laplacian argument of type %s' % type(L_norm_real))
+
+
+# ----------------------------------------------------------------------------
+# Reference API
+# ----------------------------------------------------------------------------
+def process(mul_L_real, mul_L_imag, weight, X_real, X_imag):
+    """One Chebyshev term (reference src/layer/sparse_magnet.py:8-18): stack([real, imag]) with
+    real = (L_re X_re - L_im X_im) W, imag = (L_im X_re + L_re X_im) W."""
+    lap = mul_L_real if isinstance(mul_L_real, MagneticLaplacian) else _lap_from_pair(mul_L_real, mul_L_imag)
+    xp = _as_packed(X_real, X_imag)
+    out = _ListConvFn.apply(xp, weight.unsqueeze(0), None, [lap], False)
+    return out.permute(1, 0, 2)
+
+
+class ChebConv(nn.Module):
+    """The MagNet convolution (reference src/layer/sparse_magnet.py:21-72).
+
+    weight [K+1, in_c, out_c] ~ U(-1/sqrt(out_c), 1/sqrt(out_c)), bias [1, out_c] zeros, the same
+    real bias added to both parts."""
+
+    def __init__(self, in_c, out_c, K, L_norm_real, L_norm_imag, bias=True):
+        super(ChebConv, self).__init__()
+        self.mul_L_real = L_norm_real
+        self.mul_L_imag = L_norm_imag
+        self._mode, self._lap, n_terms = _resolve_laplacian(L_norm_real, L_norm_imag)
+        self._n_terms = K + 1 if n_terms is None else n_terms
+        self.weight = nn.Parameter(torch.Tensor(K + 1, in_c, out_c))
+        stdv = 1. / math.sqrt(self.weight.size(-1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(1, out_c))
+            nn.init.zeros_(self.bias)
+        else:
+            self.register_parameter("bias", None)
+
+    def _laps(self):
+        if self._lap is None:                          # reference-style lists, converted on first use
+            self._lap = [_lap_from_pair(r, i) for r, i in zip(self.mul_L_real, self.mul_L_imag)]
+        return self._lap
+
+    def forward_packed(self, xp, relu=False):
+        """Row-planar in, row-planar out; `relu` fuses the following complex ReLU."""
+        if self._n_terms > self.weight.size(0):
+            raise MagnetHipError('%d Laplacian terms but weight has %d slices' % (self._n_terms, self.weight.size(0)))
+        w = self.weight[:self._n_terms]
+        if self._mode == 'cheb':
+            return _ChebConvFn.apply(xp, w, self.bias, self._laps(), relu)
+        return _ListConvFn.apply(xp, w, self.bias, self._laps(), relu)
+
+    def forward(self, data):
+        return _views(self.forward_packed(_as_packed(data[0], data[1])))
+
+
+class complex_relu_layer(nn.Module):
+    """mask = (real >= 0) applied to both parts (reference src/layer/sparse_magnet.py:75-91)."""
+
+    def __init__(self, ):
+        super(complex_relu_layer, self).__init__()
+
+    def complex_relu(self, real, img):
+        return _views(_ComplexReluFn.apply(_as_packed(real, img)))
+
+    def forward(self, real, img=None):
+        if img is None:
+            img = real[1]
+            real = real[0]
+        return self.complex_relu(real, img)
+
+
+def _run_trunk(chebs, real, imag):
+    """nn.Sequential of ChebConv / complex_relu_layer with each ReLU fused into the conv before it."""
+    p = _as_packed(real, imag)
+    mods = list(chebs)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, ChebConv):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], complex_relu_layer)
+            p = m.forward_packed(p, relu=fuse)
+            i += 2 if fuse else 1
+        elif isinstance(m, complex_relu_layer):
+            p = _ComplexReluFn.apply(p)
+            i += 1
+        else:
+            real, imag = m(_views(p))
+            p = _as_packed(real, imag)
+            i += 1
+    return p
+
+
+class ChebNet(nn.Module):
+    """Node-classification network (reference src/layer/sparse_magnet.py:94-130)."""
+
+    def __init__(self, in_c, L_norm_real, L_norm_imag, num_filter=2, K=2, label_dim=2, activation=False, layer=2,
+                 dropout=False):
+        super(ChebNet, self).__init__()
+        chebs = [ChebConv(in_c=in_c, out_c=num_filter, K=K, L_norm_real=L_norm_real, L_norm_imag=L_norm_imag)]
+        if activation:
+            chebs.append(complex_relu_layer())
+        for i in range(1, layer):
+            chebs.append(ChebConv(in_c=num_filter, out_c=num_filter, K=K, L_norm_real=L_norm_real,
+                                  L_norm_imag=L_norm_imag))
+            if activation:
+                chebs.append(complex_relu_layer())
+        self.Chebs = torch.nn.Sequential(*chebs)
+        last_dim = 2
+        self.Conv = nn.Conv1d(num_filter * last_dim, label_dim, kernel_size=1)
+        self.dropout = dropout
+
+    def forward(self, real, imag):
+        p = _run_trunk(self.Chebs, real, imag)
+        x = p.reshape(p.size(0), -1)                   # == cat((real, imag), -1): same memory
+        if self.dropout > 0:
+            x = F.dropout(x, self.dropout, training=self.training)
+        # Conv1d with kernel 1 over [1, 2F, N] is a linear map per node
+        x = F.linear(x, self.Conv.weight.squeeze(-1), self.Conv.bias)
+        x = x.t().unsqueeze(0)
+        return F.log_softmax(x, dim=1)
+
+
+class ChebNet_Edge(nn.Module):
+    """Link-prediction network (reference src/layer/sparse_magnet.py:133-165); `index` [M, 2] are
+    the node pairs to score."""
+
+    def __init__(self, in_c, L_norm_real, L_norm_imag, num_filter=2, K=2, label_dim=2, activation=False, layer=2,
+                 dropout=False):
+        super(ChebNet_Edge, self).__init__()
+        chebs = [ChebConv(in_c=in_c, out_c=num_filter, K=K, L_norm_real=L_norm_real, L_norm_imag=L_norm_imag)]
+        if activation and (layer != 1):
+            chebs.append(complex_relu_layer())
+        for i in range(1, layer):
+            chebs.append(ChebConv(in_c=num_filter, out_c=num_filter, K=K, L_norm_real=L_norm_real,
+                                  L_norm_imag=L_norm_imag))
+            if activation:
+                chebs.append(complex_relu_layer())
+        self.Chebs = torch.nn.Sequential(*chebs)
+        last_dim = 2
+        self.linear = nn.Linear(num_filter * last_dim * 2, label_dim)
+        self.dropout = dropout
+
+    def forward(self, real, imag, index):
+        p = _run_trunk(self.Chebs, real, imag)
+        real, imag = p[:, 0, :], p[:, 1, :]
+        x = torch.cat((real[index[:, 0]], real[index[:, 1]], imag[index[:, 0]], imag[index[:, 1]]), dim=-1)
+        if self.dropout > 0:
+            x = F.dropout(x, self.dropout, training=self.training)
+        x = self.linear(x)
+        return F.log_softmax(x, dim=1)
+
+
+class MagNetConv(nn.Module):
+    """ChebConv that takes the graph at call time: forward(real, imag, edge_index, edge_weight=None).
+    The magnetic Laplacian of (edge_index, edge_weight, q) is built on the GPU and cached until a
+    different graph tensor is passed."""
+
+    def __init__(self, in_c, out_c, K, q=0.25, bias=True):
+        super(MagNetConv, self).__init__()
+        self.K, self.q = K, q
+        self.weight = nn.Parameter(torch.Tensor(K + 1, in_c, out_c))
+        stdv = 1. / math.sqrt(out_c)
+        self.weight.data.uniform_(-stdv, stdv)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(1, out_c))
+        else:
+            self.register_parameter("bias", None)
+        self._cache = None
+
+    def laplacian(self, edge_index, edge_weight, n):
+        c = self._cache
+        if c is not None and c[0] is edge_index and c[1] is edge_weight and c[2] == n:
+            return c[3]
+        lap = build_magnetic_laplacian(edge_index[0], edge_index[1], n, q=self.q, edge_weight=edge_weight,
+                                       device=edge_index.device if edge_index.is_cuda else None)
+        self._cache = (edge_index, edge_weight, n, lap)
+        return lap
+
+    def forward(self, real, imag, edge_index, edge_weight=None):
+        lap = self.laplacian(edge_index, edge_weight, real.size(0))
+        return _views(_ChebConvFn.apply(_as_packed(real, imag), self.weight, self.bias, lap, False))

@@ -1,0 +1,58 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the header declares,
+and rejects bad arguments before touching a device.  No compute is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'magnet_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mh_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from magnet_amd import _lib
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(_lib.lib, n), 'libmagnet_hip.so does not export %s' % n
+    assert sorted(_lib.EXPORTS) == names
+    assert _lib.lib.mh_version() >= 100
+
+
+def test_bad_arguments_are_rejected_without_a_device():
+    from magnet_amd import _lib
+    lib = _lib.lib
+    rc = lib.mh_cspmm(None, None, None, -1, None, 0, 0, None, 0, 0, 1.0, None, 0, 0, 0.0, None, 0, 0, 0.0,
+                      None, 0, None, 4, None)
+    assert rc == -1 and b'n_rows' in lib.mh_last_error()
+    rc = lib.mh_cspmm(None, None, None, 5, None, 4, 4, None, 4, 4, 1.0, None, 0, 0, 0.0, None, 0, 0, 0.0,
+                      None, 0, None, 4, None)
+    assert rc == -1 and b'null' in lib.mh_last_error()
+    nnz = C.c_int64(0)
+    rc = lib.mh_lap_build_count(None, None, 1, None, 10, 5, 2.0, 0, None, 0, None, C.byref(nnz), None)
+    assert rc == -1
+    assert lib.mh_pack(None, 0, None, 0, None, 0, 0, -3, 4, None) == -1
+    assert lib.mh_powerlaw_edges(0, 10, 1, 0, None, None, None) == -1
+    with pytest.raises(_lib.MagnetHipError):
+        _lib.check(rc)
+
+
+def test_workspace_size_grows_with_the_graph():
+    from magnet_amd import _lib
+    a = _lib.lib.mh_lap_workspace_bytes(1000, 100, 0, 0)
+    b = _lib.lib.mh_lap_workspace_bytes(100000, 100, 0, 0)
+    c = _lib.lib.mh_lap_workspace_bytes(100000, 100, 1, 0)
+    assert 0 < a < b < c
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from magnet_amd import MagnetHipError, pack_complex
+    with pytest.raises(MagnetHipError):
+        pack_complex(torch.zeros(3, 4), torch.zeros(3, 4))

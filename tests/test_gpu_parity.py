@@ -1,0 +1,428 @@
+"""Parity of the HIP path (through the C ABI of libmagnet_hip.so) with the CPU oracle and the
+golden vectors.  Needs an MI355X: every test is marked gpu.
+
+Bars: CSR structure (row_ptr / col_idx) bit-exact; values, forward and backward outputs within
+1e-5 relative in fp32 (conftest.assert_close)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_golden, assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _mods():
+    import magnet_amd
+    from magnet_amd import laplacian
+    from magnet_amd.utils import hermitian
+    from magnet_amd.layer import sparse_magnet
+    from oracle import magnet_oracle as O
+    return magnet_amd, laplacian, hermitian, sparse_magnet, O
+
+
+LAP = load_golden('lap_cases.npz')
+LAP_NAMES = [str(s) for s in LAP['names']]
+
+
+def _lap_inputs(g, k):
+    n, q, lam, gcn = g[k + '/params']
+    w = g[k + '/w'] if (k + '/w') in g.files else None
+    return g[k + '/row'], g[k + '/col'], int(n), float(q), float(lam), bool(gcn), w
+
+
+def _assert_same_csr(L, indptr, indices, data, rel=1e-5, what=''):
+    assert L.indptr.dtype == np.int32 and L.indices.dtype == np.int32 and L.dtype == np.complex64
+    assert np.array_equal(L.indptr, indptr), what + ': row_ptr differs'
+    assert np.array_equal(L.indices, indices), what + ': col_idx differs'
+    assert_close(L.data.real, data.real, rel=rel, what=what + ' re')
+    assert_close(L.data.imag, data.imag, rel=rel, what=what + ' im')
+    if len(data):
+        assert np.abs(L.data - data).max() <= rel * np.abs(data).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# Laplacian builder
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', LAP_NAMES)
+def test_builder_golden(name):
+    _, _, H, _, O = _mods()
+    row, col, n, q, lam, gcn, w = _lap_inputs(LAP, name)
+    L = H.hermitian_decomp_sparse(row, col, n, q, True, True, lam, gcn, w)
+    _assert_same_csr(L, LAP[name + '/indptr'], LAP[name + '/indices'], LAP[name + '/data'], what=name)
+    Lo = O.hermitian_decomp_sparse(row, col, n, q, True, True, lam, gcn, w)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what=name + ' vs oracle')
+
+
+def test_builder_reference_shipped_caches():
+    _, _, H, _, _ = _mods()
+    g = load_golden('telegram_cache.npz')
+    row, col, n, _, _, _, w = _lap_inputs(LAP, 'telegram_weighted_q05')
+    for tag in [str(s) for s in g['names']]:
+        q = float(tag.split('_')[0])
+        weighted = tag in ('0.05_2', '0.15_2')
+        L = H.hermitian_decomp_sparse(row, col, n, q, edge_weight=w if weighted else None)
+        _assert_same_csr(L, g[tag + '/T1/indptr'], g[tag + '/T1/indices'], g[tag + '/T1/data'], what=tag)
+
+
+def test_builder_index_dtypes_and_device_inputs():
+    _, lap, H, _, O = _mods()
+    rng = np.random.default_rng(5)
+    n, e = 300, 5000
+    row = rng.integers(0, n, e); col = rng.integers(0, n, e)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.2)
+    for conv in (lambda a: a.astype(np.int32), lambda a: torch.from_numpy(a).to(DEV),
+                 lambda a: torch.from_numpy(a.astype(np.int32)).to(DEV), lambda a: list(a)):
+        L = H.hermitian_decomp_sparse(conv(row), conv(col), n, 0.2)
+        _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6)
+
+
+def test_builder_rejects_bad_input():
+    mh, _, H, _, _ = _mods()
+    with pytest.raises(mh.MagnetHipError):
+        H.hermitian_decomp_sparse(np.array([0, 7]), np.array([1, 2]), 5, 0.25)      # endpoint out of range
+    with pytest.raises(mh.MagnetHipError):
+        H.hermitian_decomp_sparse(np.array([0, -1]), np.array([1, 2]), 5, 0.25)
+    with pytest.raises(ValueError):
+        H.hermitian_decomp_sparse(np.array([0]), np.array([1]), 5, 0.25, laplacian=False)
+    with pytest.raises(mh.MagnetHipError):
+        H.hermitian_decomp_sparse(np.array([0, 1]), np.array([1]), 5, 0.25)
+
+
+@pytest.mark.parametrize('n,e,weights', [(20000, 400000, None), (5000, 300000, 'int'), (3000, 100000, 'float'),
+                                         (1, 10, None), (70000, 50, None), (1000, 200000, 'int')])
+def test_builder_random_vs_oracle(n, e, weights):
+    _, lap, H, _, O = _mods()
+    src, dst = O.powerlaw_edges(n, e, seed=11)
+    rng = np.random.default_rng(2)
+    w = None
+    if weights == 'int':
+        w = rng.integers(1, 20, e).astype(np.float32)
+    elif weights == 'float':
+        w = rng.random(e).astype(np.float32) + 0.05
+    L = H.hermitian_decomp_sparse(src, dst, n, 0.25, edge_weight=w)
+    Lo = O.hermitian_decomp_sparse(src, dst, n, 0.25, edge_weight=w)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what='powerlaw n=%d' % n)
+
+
+def test_generator_matches_oracle():
+    _, lap, _, _, O = _mods()
+    for n, e, seed, first in [(1000, 5000, 42, 0), (2_000_000, 100000, 43, 7_000_000_000), (3, 100, 1, 5)]:
+        s, d = lap.powerlaw_edges(n, e, seed, first, device=DEV)
+        so, do = O.powerlaw_edges(n, e, seed, first)
+        assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(d.cpu().numpy(), do)
+
+
+def test_builder_full_size_properties():
+    """Config-4 sized graph (2M nodes / 40M edges): properties that hold at any size."""
+    _, lap, H, _, _ = _mods()
+    n, e = 2_000_000, 40_000_000
+    src, dst = lap.powerlaw_edges(n, e, 42, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    rp = L.row_ptr.long()
+    assert int(rp[0]) == 0 and int(rp[-1]) == L.nnz and bool((rp[1:] >= rp[:-1]).all())
+    assert L.nnz % 2 == 0 and L.nnz <= 2 * e
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), rp[1:] - rp[:-1])
+    cols = L.col_idx.long()
+    assert bool((rows != cols).all())                                   # no diagonal for lambda_max = 2
+    key = rows * n + cols
+    assert bool((key[1:] > key[:-1]).all())                             # sorted, no duplicates
+    A = L.adjoint()                                                     # Hermitian: L^H has the same CSR
+    assert torch.equal(A.row_ptr, L.row_ptr) and torch.equal(A.col_idx, L.col_idx)
+    assert float((A.val - L.val).abs().max()) <= 2e-7
+    mod = torch.sqrt(L.val[:, 0] ** 2 + L.val[:, 1] ** 2)
+    assert float(mod.max()) <= 1.0 + 1e-6 and float(mod.min()) > 0
+    # q = 0.25 and integer weight differences: every phase is a multiple of pi/2
+    ang = torch.atan2(-L.val[:, 1], -L.val[:, 0]) / (np.pi / 2)
+    assert float((ang - ang.round()).abs().max()) < 1e-3
+    del A, rows, cols, key
+    # degrees: d^-1/2 came back
+    assert L.dinv.numel() == n and float(L.dinv.max()) <= 2 ** 0.5 + 1e-6    # d >= 1/2 or d := 1
+
+
+# ---------------------------------------------------------------------------------------------
+# fused complex SpMM
+# ---------------------------------------------------------------------------------------------
+def _rand_packed(n, f, seed, ld=None, im=None):
+    g = torch.Generator().manual_seed(seed)
+    if ld is None:
+        return torch.randn(n, 2, f, generator=g).to(DEV)
+    buf = torch.full((n, ld), 7.0)                  # poison the padding
+    x = torch.as_strided(buf, (n, 2, f), (ld, im, 1))
+    x.copy_(torch.randn(n, 2, f, generator=g))
+    return torch.as_strided(buf.to(DEV), (n, 2, f), (ld, im, 1))
+
+
+def _to_c(p):
+    p = p.detach().cpu().double().numpy()
+    return p[:, 0, :] + 1j * p[:, 1, :]
+
+
+def _spmm_case(L, Ls, f, seed, alpha=1.0, use_z1=False, use_z2=False, bias=False, relu=False, strided=False):
+    n = L.n_rows
+    if strided:
+        X = _rand_packed(n, f, seed, ld=2 * f + 8, im=f + 4)
+        out = torch.as_strided(torch.zeros(n, 3 * f + 12, device=DEV), (n, 2, f), (3 * f + 12, f + 8, 1))
+    else:
+        X = _rand_packed(n, f, seed); out = None
+    z1 = _rand_packed(n, f, seed + 1) if use_z1 else None
+    z2 = _rand_packed(n, f, seed + 2) if use_z2 else None
+    b = torch.randn(f, generator=torch.Generator().manual_seed(seed + 3)).to(DEV) if bias else None
+    mask = torch.zeros(n, f, dtype=torch.uint8, device=DEV) if relu else None
+    Y = L.spmm(X, out=out, alpha=alpha, z1=z1, beta1=0.5, z2=z2, beta2=-1.0, bias=b, relu=relu, mask=mask)
+    ref = alpha * (Ls @ _to_c(X))
+    if use_z1:
+        ref = ref + 0.5 * _to_c(z1)
+    if use_z2:
+        ref = ref - _to_c(z2)
+    if bias:
+        bb = b.cpu().double().numpy()
+        ref = ref + bb + 1j * bb
+    got = _to_c(Y)
+    if relu:
+        # entries whose real part is within rounding of 0 may gate either way; exclude them
+        safe = np.abs(ref.real) > 1e-4 * max(np.abs(ref).max(), 1.0)
+        m = (ref.real >= 0)
+        ref = ref * m
+        assert np.array_equal(mask.cpu().numpy().astype(bool)[safe], m[safe])
+        got = np.where(safe, got, ref)
+    assert_close(got.real, ref.real, what='re F=%d' % f)
+    assert_close(got.imag, ref.imag, what='im F=%d' % f)
+
+
+@pytest.fixture(scope='module')
+def small_graph():
+    _, lap, H, _, O = _mods()
+    n, e = 3000, 60000
+    src, dst = O.powerlaw_edges(n, e, seed=3)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.1)
+    return L, L.to_scipy().astype(np.complex128)
+
+
+@pytest.mark.parametrize('f', [1, 2, 3, 4, 5, 7, 8, 12, 16, 20, 32, 48, 64, 100, 128, 200, 256, 260, 512, 1024, 1028, 2048])
+def test_spmm_feature_widths(small_graph, f):
+    L, Ls = small_graph
+    _spmm_case(L, Ls, f, seed=f)
+
+
+@pytest.mark.parametrize('f', [4, 16, 128, 256, 6])
+def test_spmm_epilogues(small_graph, f):
+    L, Ls = small_graph
+    _spmm_case(L, Ls, f, 1, alpha=2.0, use_z1=True)
+    _spmm_case(L, Ls, f, 2, alpha=2.0, use_z1=True, use_z2=True)
+    _spmm_case(L, Ls, f, 3, alpha=-0.7, use_z1=True, use_z2=True, bias=True, relu=True)
+    _spmm_case(L, Ls, f, 4, bias=True)
+    _spmm_case(L, Ls, f, 5, relu=True)
+    _spmm_case(L, Ls, f, 6, alpha=1.5, use_z1=True, strided=True)
+
+
+def test_spmm_in_place_axpy_and_edge_cases(small_graph):
+    _, lap, H, _, O = _mods()
+    L, Ls = small_graph
+    X = _rand_packed(L.n_rows, 16, 1); Z = _rand_packed(L.n_rows, 16, 2)
+    ref = 2.0 * (Ls @ _to_c(X)) - _to_c(Z)
+    L.spmm(X, out=Z, alpha=2.0, z1=Z, beta1=-1.0)               # Y aliases Z1
+    assert_close(_to_c(Z).real, ref.real); assert_close(_to_c(Z).imag, ref.imag)
+    # graph with no kept entries, empty rows, and a single hub row
+    E = lap.build_magnetic_laplacian(np.array([0, 1]), np.array([1, 0]), 6, q=0.25)
+    assert E.nnz == 0
+    Xe = _rand_packed(6, 8, 3)
+    assert float(E.spmm(Xe).abs().max()) == 0.0
+    assert torch.equal(E.spmm(Xe, z1=Xe, beta1=1.0), Xe)
+    n = 5000
+    hub = lap.build_magnetic_laplacian(np.zeros(n - 1, np.int64), np.arange(1, n), n, q=0.25)
+    Xh = _rand_packed(n, 32, 4)
+    refh = hub.to_scipy().astype(np.complex128) @ _to_c(Xh)
+    got = _to_c(hub.spmm(Xh))
+    assert_close(got.real, refh.real); assert_close(got.imag, refh.imag)
+    mh = _mods()[0]
+    with pytest.raises(mh.MagnetHipError):
+        L.spmm(X, out=X)
+    with pytest.raises(mh.MagnetHipError):
+        L.spmm(_rand_packed(L.n_rows + 1, 16, 1))
+
+
+def test_spmm_is_deterministic_and_linear():
+    """Mid-size power-law graph: bitwise reproducible; L(aX + bY) = a LX + b LY; Hermitian form real."""
+    _, lap, _, _, _ = _mods()
+    n, e, f = 200_000, 4_000_000, 128
+    src, dst = lap.powerlaw_edges(n, e, 9, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    X = _rand_packed(n, f, 1); Y = _rand_packed(n, f, 2)
+    a, b = 0.75, -1.25
+    lx, ly = L.spmm(X), L.spmm(Y)
+    assert torch.equal(lx, L.spmm(X))
+    comb = L.spmm(a * X + b * Y)
+    ref = a * lx + b * ly
+    assert float((comb - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # <X, L X> is real for Hermitian L
+    xc = torch.complex(X[:, 0, :].double(), X[:, 1, :].double()); lc = torch.complex(lx[:, 0, :].double(), lx[:, 1, :].double())
+    form = (xc.conj() * lc).sum()
+    assert abs(form.imag.item()) <= 1e-6 * abs(form.real.item()) + 1e-3
+    # against the vendor CSR SpMM (four real products), an independent implementation at this size
+    rp, ci = L.row_ptr.long(), L.col_idx.long()
+    Lre = torch.sparse_csr_tensor(rp, ci, L.val[:, 0].contiguous(), size=(n, n))
+    Lim = torch.sparse_csr_tensor(rp, ci, L.val[:, 1].contiguous(), size=(n, n))
+    xr, xi = X[:, 0, :].contiguous(), X[:, 1, :].contiguous()
+    re = Lre @ xr - Lim @ xi; im = Lim @ xr + Lre @ xi
+    scale = float(lx.abs().max())
+    assert float((lx[:, 0, :] - re).abs().max()) <= 1e-5 * scale
+    assert float((lx[:, 1, :] - im).abs().max()) <= 1e-5 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# layers against the golden vectors (reference outputs)
+# ---------------------------------------------------------------------------------------------
+CONV = load_golden('conv_cases.npz')
+
+
+def _telegram(q, weighted):
+    row, col, n, _, _, _, w = _lap_inputs(LAP, 'telegram_weighted_q05')
+    return row, col, n, (w if weighted else None)
+
+
+@pytest.mark.parametrize('mode', ['basis', 'reference_lists'])
+@pytest.mark.parametrize('name', [str(s) for s in CONV['names']])
+def test_chebconv_forward_backward(name, mode):
+    _, lap, H, M, O = _mods()
+    K, cin, cout, q, weighted = CONV[name + '/params']
+    K, cin, cout = int(K), int(cin), int(cout)
+    row, col, n, w = _telegram(float(q), bool(weighted))
+    if mode == 'basis':
+        basis = H.cheb_poly_sparse(H.hermitian_decomp_sparse_device(row, col, n, float(q), edge_weight=w), K)
+        Lr, Li = basis, None
+    else:
+        Lo = O.hermitian_decomp_sparse(row, col, n, float(q), edge_weight=w)
+        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, K))
+        Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
+    conv = M.ChebConv(cin, cout, K, Lr, Li).to(DEV)
+    assert tuple(conv.weight.shape) == (K + 1, cin, cout) and tuple(conv.bias.shape) == (1, cout)
+    t = lambda k: torch.from_numpy(CONV[name + '/' + k].copy()).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(t('weight')); conv.bias.copy_(t('bias'))
+    Xr = t('Xr').requires_grad_(True); Xi = t('Xi').requires_grad_(True)
+    real, imag = conv((Xr, Xi))
+    ((real * t('Gr')).sum() + (imag * t('Gi')).sum()).backward()
+    c = lambda x: x.detach().cpu().numpy()
+    assert_close(c(real), CONV[name + '/real'], what='real')
+    assert_close(c(imag), CONV[name + '/imag'], what='imag')
+    assert_close(c(conv.weight.grad), CONV[name + '/dweight'], what='dW')
+    assert_close(c(conv.bias.grad), CONV[name + '/dbias'], what='db')
+    assert_close(c(Xr.grad), CONV[name + '/dXr'], what='dXr')
+    assert_close(c(Xi.grad), CONV[name + '/dXi'], what='dXi')
+
+
+def test_process_matches_oracle():
+    _, lap, H, M, O = _mods()
+    row, col, n, w = _telegram(0.25, False)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.25)
+    Lr, Li = O.laplacian_lists([Lo])
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(6, 9, generator=g); Xr = torch.randn(n, 6, generator=g); Xi = torch.randn(n, 6, generator=g)
+    ref = O.process(Lr[0], Li[0], W, Xr, Xi)
+    got = M.process(Lr[0].to(DEV), Li[0].to(DEV), W.to(DEV), Xr.to(DEV), Xi.to(DEV))
+    assert tuple(got.shape) == (2, n, 9)
+    assert_close(got.cpu().numpy(), ref.numpy(), what='process')
+
+
+def test_complex_relu_layer():
+    _, _, _, M, O = _mods()
+    g = torch.Generator().manual_seed(1)
+    real = torch.randn(50, 7, generator=g); imag = torch.randn(50, 7, generator=g)
+    real[0, 0] = 0.0; real[1, 1] = -0.0
+    rr, ri = O.complex_relu(real, imag)
+    a = real.to(DEV).requires_grad_(True); b = imag.to(DEV).requires_grad_(True)
+    gr, gi = M.complex_relu_layer()(a, b)
+    assert torch.equal(gr.cpu(), rr) and torch.equal(gi.cpu(), ri)
+    gr2, gi2 = M.complex_relu_layer()((a, b))
+    assert torch.equal(gr2.cpu(), rr)
+    (gr.sum() + 2 * gi.sum()).backward()
+    m = (real >= 0).float()
+    assert torch.equal(a.grad.cpu(), m) and torch.equal(b.grad.cpu(), 2 * m)
+
+
+NET = load_golden('net_cases.npz')
+
+
+@pytest.mark.parametrize('mode', ['basis', 'reference_lists'])
+@pytest.mark.parametrize('name', [str(s) for s in NET['names']])
+def test_networks_forward_backward(name, mode):
+    _, lap, H, M, O = _mods()
+    K, layer, act, F, q, cin = NET[name + '/params']
+    K, layer, act, F, cin = int(K), int(layer), bool(act), int(F), int(cin)
+    row, col, n, _ = _telegram(float(q), False)
+    if mode == 'basis':
+        Lr, Li = H.cheb_poly_sparse(H.hermitian_decomp_sparse_device(row, col, n, float(q)), K), None
+    else:
+        Lo = O.hermitian_decomp_sparse(row, col, n, float(q))
+        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, K))
+        Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
+    pre = name + '/state/'
+    state = {k[len(pre):]: torch.from_numpy(NET[k].copy()) for k in NET.files if k.startswith(pre)}
+    X = torch.from_numpy(NET[name + '/X']).to(DEV)
+    Xr = X.clone().requires_grad_(True); Xi = X.clone().requires_grad_(True)
+    c = lambda x: x.detach().cpu().numpy()
+    if name.startswith('node'):
+        y = torch.from_numpy(NET[name + '/y'])
+        net = M.ChebNet(cin, Lr, Li, num_filter=F, K=K, label_dim=int(y.max()) + 1, activation=act, layer=layer,
+                        dropout=0.0).to(DEV)
+        assert sorted(net.state_dict().keys()) == sorted(state.keys())
+        net.load_state_dict(state)
+        preds = net(Xr, Xi)
+        assert tuple(preds.shape) == (1, int(y.max()) + 1, n)
+        train = torch.from_numpy(NET[name + '/train']).to(DEV)
+        loss = torch.nn.NLLLoss()(preds[:, :, train], y[None].to(DEV)[:, train])
+        assert_close(c(preds), NET[name + '/preds'], what='preds')
+    else:
+        net = M.ChebNet_Edge(cin, Lr, Li, num_filter=F, K=K, label_dim=3, activation=act, layer=layer, dropout=0.0).to(DEV)
+        assert sorted(net.state_dict().keys()) == sorted(state.keys())
+        net.load_state_dict(state)
+        out = net(Xr, Xi, torch.from_numpy(NET[name + '/pairs']).to(DEV))
+        loss = torch.nn.functional.nll_loss(out, torch.from_numpy(NET[name + '/y']).to(DEV))
+        assert_close(c(out), NET[name + '/out'], what='out')
+    loss.backward()
+    assert abs(loss.item() - float(NET[name + '/loss'])) <= 1e-5 * abs(float(NET[name + '/loss'])) + 1e-6
+    for k, p in net.named_parameters():
+        assert_close(c(p.grad), NET[name + '/grad/' + k], what='grad ' + k)
+    assert_close(c(Xr.grad), NET[name + '/dXr'], what='dXr')
+    assert_close(c(Xi.grad), NET[name + '/dXi'], what='dXi')
+
+
+def test_citeseer_link_prediction_step():
+    """Config-3 shaped step: CiteSeer graph, K=2, q=0.1, 16 filters, degree features, fwd + bwd."""
+    _, lap, H, M, O = _mods()
+    g = load_golden('citeseer_link_case.npz')
+    n = int(g['n'])
+    L = H.hermitian_decomp_sparse_device(g['row'], g['col'], n, 0.1)
+    Ls = L.to_scipy()
+    assert np.array_equal(Ls.indptr, g['indptr']) and np.array_equal(Ls.indices, g['indices'])
+    assert_close(Ls.data.real, g['data'].real); assert_close(Ls.data.imag, g['data'].imag)
+    state = {k[6:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith('state/')}
+    X = torch.from_numpy(g['X']).to(DEV)
+    net = M.ChebNet_Edge(X.size(-1), H.cheb_poly_sparse(L, 2), None, num_filter=16, K=2, label_dim=3,
+                         activation=True, layer=2, dropout=0.0).to(DEV)
+    net.load_state_dict(state)
+    out = net(X.clone(), X.clone(), torch.from_numpy(g['pairs']).to(DEV))
+    loss = torch.nn.functional.nll_loss(out, torch.from_numpy(g['y']).to(DEV))
+    loss.backward()
+    assert_close(out.detach().cpu().numpy(), g['out'], what='out')
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    for k, p in net.named_parameters():
+        assert_close(p.grad.cpu().numpy(), g['grad/' + k], what='grad ' + k)
+
+
+def test_magnetconv_edge_index_signature():
+    _, lap, H, M, O = _mods()
+    row, col, n, _ = _telegram(0.25, False)
+    ei = torch.from_numpy(np.vstack([row, col])).to(DEV)
+    conv = M.MagNetConv(5, 7, K=2, q=0.25).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    Xr = torch.randn(n, 5, generator=g).to(DEV); Xi = torch.randn(n, 5, generator=g).to(DEV)
+    real, imag = conv(Xr, Xi, ei)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.25)
+    rr, ri = O.cheb_conv_recursion(Lo, conv.weight.detach().cpu(), conv.bias.detach().cpu(), Xr.cpu(), Xi.cpu())
+    assert_close(real.detach().cpu().numpy(), rr.numpy()); assert_close(imag.detach().cpu().numpy(), ri.numpy())
+    assert conv.laplacian(ei, None, n) is conv.laplacian(ei, None, n)          # cached per graph tensor
