@@ -15,6 +15,11 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr, require_cuda, MagnetHipError
 
 
+# Optional observer of SpMM launches: set to a callable(start_event, end_event, info) to have every
+# spmm() bracketed by HIP events on the stream it launches on (used by bench.py for per-kernel times).
+SPMM_OBSERVER = None
+
+
 def _packed_strides(t, what):
     """(ld, im) of a row-planar complex tensor [N, 2, F] (last dim contiguous)."""
     if t.dim() != 3 or t.size(1) != 2 or t.dtype != torch.float32:
@@ -96,9 +101,16 @@ class MagneticLaplacian:
                 raise MagnetHipError('bias has %d entries, expected %d' % (bias.numel(), f))
         if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != self.n_rows * f or not mask.is_contiguous()):
             raise MagnetHipError('mask must be contiguous uint8 [n_rows, F]')
+        obs = SPMM_OBSERVER
+        if obs is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(X.device))
         check(_lib.lib.mh_cspmm(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), self.n_rows,
                                 ptr(X), ldx, imx, ptr(out), ldy, imy, float(alpha), *zargs,
                                 ptr(bias), int(bool(relu)), ptr(mask), f, stream_ptr(X.device)))
+        if obs is not None:
+            ev1.record(torch.cuda.current_stream(X.device))
+            obs(ev0, ev1, dict(nnz=self.nnz, n_rows=self.n_rows, F=f, n_addends=int(z1 is not None) + int(z2 is not None)))
         return out
 
     # -- conversions ----------------------------------------------------------

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/profile_bench.sh (gpurun_out/prof) into the summaries kept
+under profiles/:  <tag>_kernel_stats.csv (per-kernel time of the bench run), <tag>_hbm_counters.csv
+(FETCH_SIZE / WRITE_SIZE per launch of the kernels that matter) and spmm_traffic.json (HBM bytes
+per SpMM launch, which bench.py reports as roofline.traffic).
+
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950
+FETCH_SIZE reports half the bytes of 16-byte-per-lane coalesced reads (checked here on the
+bias/ReLU kernel, whose traffic is known exactly: it reads and writes every output byte once).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out', 'prof')
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+    for r in rows:
+        name = r['Name']
+        if name.startswith('Cijk_'):
+            name = name[:60] + '... (hipBLASLt fp32 GEMM)'
+        elif len(name) > 160:
+            name = name[:160] + '...'
+        w.writerow([name, r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+
+bench = json.loads(open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines()[-1])
+per = {}
+for kind in ('fetch', 'write'):
+    path = glob.glob(os.path.join(src, kind, '*', '*_counter_collection.csv'))[0]
+    for r in csv.DictReader(open(path)):
+        n = r['Kernel_Name']
+        key = 'cspmm' if 'cspmm' in n else 'bias_relu' if 'bias_relu' in n else 'gemm' if n.startswith('Cijk_') else None
+        if key:
+            per.setdefault((key, kind), []).append(
+                (float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+with open(os.path.join(dst, tag + '_hbm_counters.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'counter', 'launch', 'raw_KiB', 'bytes_corrected', 'duration_ms_under_pmc'])
+    for (key, kind), vals in sorted(per.items()):
+        for i, (v, ms) in enumerate(vals):
+            w.writerow([key, 'FETCH_SIZE' if kind == 'fetch' else 'WRITE_SIZE', i, v,
+                        v * 1024 * (2 if kind == 'fetch' else 1), '%.3f' % ms])
+mean = lambda xs: sum(xs) / len(xs)
+fetch = mean([v for v, _ in per[('cspmm', 'fetch')]]) * 1024 * 2
+write = mean([v for v, _ in per[('cspmm', 'write')]]) * 1024
+cal_f = mean([v for v, _ in per[('bias_relu', 'fetch')]]) * 1024 * 2
+cal_w = mean([v for v, _ in per[('bias_relu', 'write')]]) * 1024
+nnz = bench['config']['nnz']
+import re
+m = re.search(r'N=(\d+) E=(\d+).*?, (\d+) complex features', bench['config']['workload'])
+out = {'nodes': int(m.group(1)), 'edges': int(m.group(2)), 'features': int(m.group(3)), 'nnz': nnz,
+       'hbm_bytes_per_launch': fetch + write, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
+       'algorithmic_bytes_per_launch': bench['roofline']['algorithmic_bytes_per_launch'],
+       'calibration': {'kernel': 'bias_relu_kernel', 'expected_bytes_each_way': int(m.group(1)) * 8 * int(m.group(3)),
+                       'measured_read_corrected': cal_f, 'measured_write': cal_w},
+       'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s' % tag}
+json.dump(out, open(os.path.join(dst, 'spmm_traffic.json'), 'w'), indent=1)
+open(os.path.join(dst, tag + '_bench_under_rocprof.json'), 'w').write(json.dumps(bench) + '\n')
+print(json.dumps(out, indent=1))
