@@ -1,0 +1,170 @@
+"""Row-partitioned propagation over the GPUs of one node (one process per GPU, torch.distributed:
+backend "nccl" = RCCL over xGMI on MI355X, "gloo" for CPU rehearsal of the exchange logic).
+
+The reference is single-device (src/sparse_Magnet.py:23-24); this module is the graph-scale
+extension of its propagation (src/layer/sparse_magnet.py:50-72).
+
+Decomposition
+-------------
+* Rows of the Laplacian (and of every feature matrix) are cut into `world` contiguous blocks
+  balanced by work (nonzeros + rows).  Rank p computes rows [b_p, b_{p+1}) of each order.
+* Every rank keeps FULL-height feature buffers [N, 2, F] indexed by global node id (288 GB of
+  HBM make that affordable: 20 GB per order at N = 10M, F = 256), so the CSR keeps its global
+  column ids and the exchange needs no packing: after computing its block of Z_k a rank sends that
+  block to every peer and receives the peers' blocks straight into place.  The transfers are
+  point-to-point sends/receives issued as one batch: on the fully connected xGMI mesh every pair
+  of GPUs has its own link, so all 7 peers are served concurrently (a ring would push 7x the
+  bytes through one link).
+* To overlap the exchange with compute the local block of the Laplacian is split by COLUMN into
+  L_int (columns inside the rank's own row block: operands already local) and L_ext (all other
+  columns).  Order k runs  Z_k[blk] = a L_int Z_{k-1} + b Z_{k-2}[blk]  while the exchange of
+  Z_{k-1} is still in flight, waits for it, then adds  a L_ext Z_{k-1}.  That covers more than
+  the interior-row split (rows without any remote column): every nonzero with a local column
+  overlaps, whatever row it sits in.
+* The weight GEMM and the bias act on rows independently, so the output block needs no exchange;
+  a conv of K orders performs K-1 exchanges.  Weight gradients are all-reduced (tiny).
+"""
+import torch
+import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------
+# partition plan (plain tensor code: runs on CPU tensors for the gloo tests and on the GPU)
+# ---------------------------------------------------------------------------------------------
+def partition_bounds(row_ptr, world, row_cost=2):
+    """world+1 row boundaries; blocks balanced by nnz + row_cost * rows (a row costs about two
+    feature-row accesses besides its gathers: the output store and the axpy operand)."""
+    n = row_ptr.numel() - 1
+    cost = row_ptr.to(torch.int64) + row_cost * torch.arange(n + 1, device=row_ptr.device, dtype=torch.int64)
+    total = int(cost[-1])
+    targets = torch.tensor([total * p // world for p in range(1, world)], device=row_ptr.device, dtype=torch.int64)
+    inner = torch.searchsorted(cost, targets).clamp_(0, n).tolist() if world > 1 else []
+    bounds = [0] + [int(b) for b in inner] + [n]
+    for i in range(1, len(bounds)):                      # keep it monotone for degenerate inputs
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+def slice_rows(row_ptr, col_idx, val, r0, r1):
+    """CSR of rows [r0, r1) (column ids unchanged)."""
+    a, b = int(row_ptr[r0]), int(row_ptr[r1])
+    rp = (row_ptr[r0:r1 + 1] - row_ptr[r0]).to(torch.int32)
+    return rp, col_idx[a:b], val[a:b]
+
+
+def split_columns(row_ptr, col_idx, val, c0, c1):
+    """Split a CSR into (entries with c0 <= col < c1, the rest); both keep all rows."""
+    n_rows = row_ptr.numel() - 1
+    inside = (col_idx >= c0) & (col_idx < c1)
+    counts = (row_ptr[1:] - row_ptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=row_ptr.device), counts)
+    out = []
+    for m in (inside, ~inside):
+        cnt = torch.bincount(rows[m], minlength=n_rows)
+        rp = torch.zeros(n_rows + 1, dtype=torch.int64, device=row_ptr.device)
+        rp[1:] = torch.cumsum(cnt, 0)
+        out.append((rp.to(torch.int32), col_idx[m].contiguous(), val[m].contiguous()))
+    return out[0], out[1]
+
+
+def exchange_blocks(full, bounds, rank, world, group=None):
+    """Send rows [bounds[rank], bounds[rank+1]) of `full` to every peer and receive every peer's
+    block into its place.  Returns the list of work handles (wait on all before reading remote rows)."""
+    if world == 1:
+        return []
+    mine = full[bounds[rank]:bounds[rank + 1]]
+    ops = []
+    for step in range(1, world):                         # staggered peers: rank r talks to r+step / r-step
+        to, frm = (rank + step) % world, (rank - step) % world
+        if mine.numel():
+            ops.append(dist.P2POp(dist.isend, mine, to, group))
+        blk = full[bounds[frm]:bounds[frm + 1]]
+        if blk.numel():
+            ops.append(dist.P2POp(dist.irecv, blk, frm, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def wait_all(works):
+    for w in works:
+        w.wait()
+
+
+class RowPartition:
+    """The rank's share of a Laplacian: its row block split into local-column and remote-column
+    parts, and the exchange of freshly computed row blocks.  `make_operator(rp, ci, val, n_cols)`
+    turns CSR tensors into an object with .spmm(X, out=, alpha=, z1=, beta1=) — the HIP
+    MagneticLaplacian in production."""
+
+    def __init__(self, row_ptr, col_idx, val, n, rank, world, make_operator, group=None):
+        self.n, self.rank, self.world, self.group = n, rank, world, group
+        self.bounds = partition_bounds(row_ptr, world)
+        self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        rp, ci, v = slice_rows(row_ptr, col_idx, val, self.r0, self.r1)
+        self.local_nnz = int(ci.numel())
+        (rpi, cii, vi), (rpe, cie, ve) = split_columns(rp, ci, v, self.r0, self.r1)
+        self.L_int = make_operator(rpi, cii, vi, n)
+        self.L_ext = make_operator(rpe, cie, ve, n)
+
+    def block(self, full):
+        return full[self.r0:self.r1]
+
+    def exchange(self, full):
+        return exchange_blocks(full, self.bounds, self.rank, self.world, self.group)
+
+    def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=()):
+        """z_out[blk] = alpha * (L z_prev)[blk] + beta * z_prev2[blk].  `pending` are the handles of
+        the exchange that completes z_prev; only the remote-column part waits for them."""
+        blk = self.block(z_out)
+        self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta)
+        wait_all(pending)
+        self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
+        return blk
+
+    def cheb_terms(self, x_full, n_terms, buffers=None):
+        """Row blocks of [T_0 x, ..., T_{n-1} x]; x_full must be complete on every rank.
+        Returns (list of full-height buffers, handles of the last exchange or [])."""
+        zs = [x_full]
+        pending = []
+        for k in range(1, n_terms):
+            z = buffers[k - 1] if buffers is not None else torch.empty_like(x_full)
+            if k == 1:
+                self.propagate(zs[0], z, 1.0, pending=pending)
+            else:
+                self.propagate(zs[k - 1], z, 2.0, zs[k - 2], -1.0, pending=pending)
+            zs.append(z)
+            pending = self.exchange(z) if k < n_terms - 1 else []
+        return zs
+
+
+class RowPartitionedConv:
+    """One MagNetConv forward on a row-partitioned graph (what bench.py times with --gpus N > 1):
+    K propagation orders with K-1 block exchanges, then the row-local weight GEMMs and bias."""
+
+    def __init__(self, lap, in_c, out_c, K, rank, world, device, seed=1):
+        from .laplacian import MagneticLaplacian
+
+        def make(rp, ci, v, n_cols):
+            return MagneticLaplacian(rp, ci, v, n_cols)
+
+        self.part = RowPartition(lap.row_ptr, lap.col_idx, lap.val, lap.n_rows, rank, world, make)
+        self.K = K
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        stdv = 1.0 / out_c ** 0.5
+        self.weight = ((torch.rand(K + 1, in_c, out_c, generator=g) * 2 - 1) * stdv).to(device)
+        self.bias = torch.zeros(1, out_c, device=device)
+        n = lap.n_rows
+        # every rank draws the same features, so the input is complete everywhere (replicated input)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.x = torch.randn(n, 2, in_c, device=device, generator=gen)
+        self.buffers = [torch.empty_like(self.x) for _ in range(K)]
+        self.launches = []
+
+    def step(self):
+        part = self.part
+        zs = part.cheb_terms(self.x, self.K + 1, self.buffers)
+        rows = part.r1 - part.r0
+        blk = lambda z: part.block(z).reshape(rows * 2, z.size(2))
+        out = torch.addmm(self.bias, blk(zs[0]), self.weight[0])
+        for k in range(1, self.K + 1):
+            out.addmm_(blk(zs[k]), self.weight[k])
+        return out.view(rows, 2, -1)

@@ -142,11 +142,14 @@ class _ChebConvFn(torch.autograd.Function):
             saved_z = None
         else:
             zs = _cheb_terms(lap, xp, k1)
-            o2 = torch.mm(_rows2(zs[0]), w[0])
+            if bias is None:
+                o2 = torch.mm(_rows2(zs[0]), w[0])
+            else:                                          # bias rides on the first GEMM's epilogue
+                o2 = torch.addmm(bias.detach().reshape(1, cout), _rows2(zs[0]), w[0])
             for k in range(1, k1):
                 o2.addmm_(_rows2(zs[k]), w[k])
             out = o2.view(n, 2, cout)
-            mask = _bias_relu_(out, None if bias is None else bias.detach(), relu)
+            mask = _bias_relu_(out, None, relu)
             saved_z = zs
         ctx.lap, ctx.relu, ctx.gemm_first, ctx.has_bias = lap, relu, gemm_first, bias is not None
         ctx.mask = mask

@@ -1,0 +1,119 @@
+"""The row-partition / block-exchange logic with real processes: world_size 2 and 3 over gloo on
+the CPU.  The sparse operator is injected (scipy here; the HIP kernel in production), so what is
+tested is exactly the code bench.py runs with --gpus N: partition bounds, row slicing, the
+local/remote column split, the overlapped propagate order and the point-to-point exchange."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import magnet_oracle as O
+from magnet_amd import dist as D
+
+
+class ScipyOperator:
+    """CSR tensors -> object with the .spmm signature of MagneticLaplacian (CPU, test only)."""
+
+    def __init__(self, rp, ci, val, n_cols):
+        v = val.numpy().astype(np.float64)
+        self.m = sp.csr_matrix((v[:, 0] + 1j * v[:, 1], ci.numpy(), rp.numpy()), shape=(rp.numel() - 1, n_cols))
+        self.nnz = int(ci.numel())
+
+    def spmm(self, X, out, alpha=1.0, z1=None, beta1=0.0):
+        x = X[:, 0, :].double().numpy() + 1j * X[:, 1, :].double().numpy()
+        y = alpha * (self.m @ x)
+        if z1 is not None:
+            y = y + beta1 * (z1[:, 0, :].double().numpy() + 1j * z1[:, 1, :].double().numpy())
+        out[:, 0, :] = torch.from_numpy(y.real).float()
+        out[:, 1, :] = torch.from_numpy(y.imag).float()
+        return out
+
+
+def _graph(n=400, e=6000, seed=4):
+    src, dst = O.powerlaw_edges(n, e, seed)
+    L = O.hermitian_decomp_sparse(src, dst, n, 0.2)
+    val = torch.from_numpy(np.stack([L.data.real, L.data.imag], 1).astype(np.float32))
+    return L, torch.from_numpy(L.indptr), torch.from_numpy(L.indices), val
+
+
+def _worker(rank, world, port, n_terms, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        L, rp, ci, val = _graph()
+        n = L.shape[0]
+        part = D.RowPartition(rp, ci, val, n, rank, world, ScipyOperator)
+        x = torch.randn(n, 2, 5, generator=torch.Generator().manual_seed(0))
+        zs = part.cheb_terms(x, n_terms)
+        blocks = [part.block(z).clone() for z in zs]
+        # after the last exchange every earlier order is complete on every rank
+        complete = [z.clone() for z in zs[:-1]]
+        torch.save({'bounds': part.bounds, 'blocks': blocks, 'complete': complete,
+                    'nnz': (part.L_int.nnz, part.L_ext.nnz, part.local_nnz)}, os.path.join(out_dir, 'r%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_partitioned_recursion_matches_single_process(world, tmp_path):
+    n_terms = 4
+    mp.spawn(_worker, args=(world, _free_port(), n_terms, str(tmp_path)), nprocs=world, join=True)
+    L, rp, ci, val = _graph()
+    n = L.shape[0]
+    x = torch.randn(n, 2, 5, generator=torch.Generator().manual_seed(0))
+    xc = x[:, 0, :].double().numpy() + 1j * x[:, 1, :].double().numpy()
+    Ld = L.astype(np.complex128)
+    ref = [xc, Ld @ xc]
+    for k in range(2, n_terms):
+        ref.append(2 * (Ld @ ref[k - 1]) - ref[k - 2])
+    outs = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    bounds = outs[0]['bounds']
+    assert bounds[0] == 0 and bounds[-1] == n and all(o['bounds'] == bounds for o in outs)
+    assert sum(o['nnz'][2] for o in outs) == L.nnz
+    for r, o in enumerate(outs):
+        assert o['nnz'][0] + o['nnz'][1] == o['nnz'][2]
+        for k in range(n_terms):
+            got = o['blocks'][k][:, 0, :].double().numpy() + 1j * o['blocks'][k][:, 1, :].double().numpy()
+            want = ref[k][bounds[r]:bounds[r + 1]]
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(ref[k]).max()
+        for k in range(n_terms - 1):
+            got = o['complete'][k][:, 0, :].double().numpy() + 1j * o['complete'][k][:, 1, :].double().numpy()
+            assert np.abs(got - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max()
+
+
+def test_partition_bounds_balance_and_edge_cases():
+    _, rp, ci, val = _graph()
+    n = rp.numel() - 1
+    for world in (1, 2, 4, 8):
+        b = D.partition_bounds(rp, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(world))
+        cost = [int(rp[b[i + 1]] - rp[b[i]]) + 2 * (b[i + 1] - b[i]) for i in range(world)]
+        assert max(cost) <= sum(cost) / world + int((rp[1:] - rp[:-1]).max()) + 2
+    empty = torch.zeros(6, dtype=torch.int32)
+    assert D.partition_bounds(empty, 4)[-1] == 5
+    assert D.partition_bounds(torch.zeros(1, dtype=torch.int32), 2) == [0, 0, 0]
+
+
+def test_split_columns_and_slice_rows():
+    L, rp, ci, val = _graph()
+    n = L.shape[0]
+    r0, r1 = 100, 250
+    rps, cis, vs = D.slice_rows(rp, ci, val, r0, r1)
+    sub = L[r0:r1]
+    assert np.array_equal(rps.numpy(), sub.indptr) and np.array_equal(cis.numpy(), sub.indices)
+    (rpi, cii, vi), (rpe, cie, ve) = D.split_columns(rps, cis, vs, r0, r1)
+    assert bool(((cii >= r0) & (cii < r1)).all()) and bool(((cie < r0) | (cie >= r1)).all())
+    a = ScipyOperator(rpi, cii, vi, n).m + ScipyOperator(rpe, cie, ve, n).m
+    assert abs(a - sub.astype(np.complex128)).max() < 1e-7
