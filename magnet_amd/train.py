@@ -1,0 +1,48 @@
+"""The reference drivers' epoch bodies (what "epoch time" means): one full-batch training step
+(forward, loss, backward, Adam) followed by one evaluation forward.
+
+    node_epoch  — reference src/sparse_Magnet.py:143-176
+    link_epoch  — reference src/Edge_sparseMagnet.py:168-199
+Checkpoint writes (src/sparse_Magnet.py:188-197, src/Edge_sparseMagnet.py:210-215) are the caller's
+business and are not part of the timed epoch.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def node_epoch(model, opt, X_real, X_img, label, train_index, val_index, criterion=None):
+    """label: [1, N] class ids; train_index / val_index: boolean [N] masks (device tensors).
+    Returns (train_loss, train_acc, val_loss, val_acc) as device scalars (no host sync)."""
+    criterion = criterion or torch.nn.NLLLoss()
+    model.train()
+    preds = model(X_real, X_img)
+    train_loss = criterion(preds[:, :, train_index], label[:, train_index])
+    pred_label = preds.max(dim=1)[1]
+    train_acc = (pred_label[:, train_index] == label[:, train_index]).float().mean()
+    opt.zero_grad()
+    train_loss.backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        preds = model(X_real, X_img)
+        pred_label = preds.max(dim=1)[1]
+        val_loss = criterion(preds[:, :, val_index], label[:, val_index])
+        val_acc = (pred_label[:, val_index] == label[:, val_index]).float().mean()
+    return train_loss.detach(), train_acc, val_loss, val_acc
+
+
+def link_epoch(model, opt, X_real, X_img, train_index, y_train, val_index, y_val):
+    """train_index / val_index: [M, 2] node pairs, y_*: [M] class ids."""
+    model.train()
+    out = model(X_real, X_img, train_index)
+    train_loss = F.nll_loss(out, y_train)
+    train_acc = (out.max(dim=1)[1] == y_train).float().mean()
+    opt.zero_grad()
+    train_loss.backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        out = model(X_real, X_img, val_index)
+        val_loss = F.nll_loss(out, y_val)
+        val_acc = (out.max(dim=1)[1] == y_val).float().mean()
+    return train_loss.detach(), train_acc, val_loss, val_acc
