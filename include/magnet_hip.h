@@ -95,6 +95,33 @@ int mh_cspmm(const int32_t* row_ptr, const int32_t* col_idx, const float* val, i
              const float* bias, int relu, uint8_t* mask_out,
              int32_t F, void* stream);
 
+/* Hub rows.  On power-law graphs a few rows hold 10^4..10^5 nonzeros and would serialise on
+ * one wavefront.  A per-matrix plan lists the rows longer than 2*chunk nonzeros and cuts them
+ * into chunks of `chunk` nonzeros; mh_cspmm_planned gives every chunk its own wavefront, stores
+ * partial sums in `scratch` (n_chunks * 2 * F floats, caller memory) and combines them in chunk
+ * order (still deterministic).  No counterpart in the reference (torch.spmm hides its own
+ * scheduling); it is part of replacing src/layer/sparse_magnet.py:9-17 at graph scale.
+ *   mh_cspmm_plan_count -> numbers of long rows and chunks (SYNCHRONISES stream); counters2 is
+ *                          device scratch of two int32
+ *   mh_cspmm_plan_ints  -> int32 words the plan buffer needs
+ *   mh_cspmm_plan_fill  -> fills the plan buffer (device int32[mh_cspmm_plan_ints])
+ *   mh_cspmm_planned    -> mh_cspmm with a plan (plan == NULL or n_long == 0: same as mh_cspmm)
+ */
+size_t mh_cspmm_plan_ints(int32_t n_long, int32_t n_chunks);
+int mh_cspmm_plan_count(const int32_t* row_ptr, int32_t n_rows, int32_t chunk, int32_t* counters2,
+                        int32_t* n_long_host, int32_t* n_chunks_host, void* stream);
+int mh_cspmm_plan_fill(const int32_t* row_ptr, int32_t n_rows, int32_t chunk, int32_t n_long,
+                       int32_t n_chunks, int32_t* plan, void* stream);
+int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n_rows,
+                     const float* X, int64_t ldx, int64_t imx,
+                     float* Y, int64_t ldy, int64_t imy,
+                     float alpha,
+                     const float* Z1, int64_t ldz1, int64_t imz1, float beta1,
+                     const float* Z2, int64_t ldz2, int64_t imz2, float beta2,
+                     const float* bias, int relu, uint8_t* mask_out, int32_t F,
+                     const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
+                     float* scratch, size_t scratch_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Layout and activation helpers around the SpMM.
  */

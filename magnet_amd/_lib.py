@@ -40,6 +40,14 @@ def _load():
                              vp, i64, i64, f32,
                              vp, i64, i64, f32,
                              vp, C.c_int, vp, i32, vp]
+    lib.mh_cspmm_planned.restype = C.c_int
+    lib.mh_cspmm_planned.argtypes = lib.mh_cspmm.argtypes[:-1] + [vp, i32, i32, i32, vp, sz, vp]
+    lib.mh_cspmm_plan_ints.restype = sz
+    lib.mh_cspmm_plan_ints.argtypes = [i32, i32]
+    lib.mh_cspmm_plan_count.restype = C.c_int
+    lib.mh_cspmm_plan_count.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32), vp]
+    lib.mh_cspmm_plan_fill.restype = C.c_int
+    lib.mh_cspmm_plan_fill.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.mh_pack.restype = C.c_int
     lib.mh_pack.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i32, vp]
     lib.mh_bias_relu.restype = C.c_int
@@ -54,7 +62,7 @@ def _load():
 lib = _load()
 
 EXPORTS = ['mh_version', 'mh_last_error', 'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
-           'mh_cspmm', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
+           'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
 
 
 def check(rc):

@@ -63,6 +63,33 @@ class MagneticLaplacian:
         self.q = q
         self.dinv = dinv
         self._adjoint = None
+        self._plan = None
+
+    # rows longer than 2*PLAN_CHUNK nonzeros are cut into chunks that get a wavefront each
+    PLAN_CHUNK = 512
+
+    def plan(self):
+        """(plan tensor or None, n_long, n_chunks, chunk), built on first use (mh_cspmm_plan_*)."""
+        if self._plan is None:
+            lib = _lib.lib
+            chunk = self.PLAN_CHUNK
+            n_long, n_chunks = C.c_int32(0), C.c_int32(0)
+            if self.n_rows > 0 and self.nnz > 2 * chunk:
+                with torch.cuda.device(self.device):
+                    tmp = torch.empty(2, dtype=torch.int32, device=self.device)
+                    s = stream_ptr(self.device)
+                    check(lib.mh_cspmm_plan_count(ptr(self.row_ptr), self.n_rows, chunk, ptr(tmp), C.byref(n_long),
+                                                  C.byref(n_chunks), s))
+                    buf = None
+                    if n_long.value > 0:
+                        buf = torch.empty(lib.mh_cspmm_plan_ints(n_long.value, n_chunks.value), dtype=torch.int32,
+                                          device=self.device)
+                        check(lib.mh_cspmm_plan_fill(ptr(self.row_ptr), self.n_rows, chunk, n_long.value,
+                                                     n_chunks.value, ptr(buf), s))
+                    self._plan = (buf, n_long.value, n_chunks.value, chunk)
+            else:
+                self._plan = (None, 0, 0, chunk)
+        return self._plan
 
     @property
     def device(self):
@@ -105,9 +132,15 @@ class MagneticLaplacian:
         if obs is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(X.device))
-        check(_lib.lib.mh_cspmm(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), self.n_rows,
-                                ptr(X), ldx, imx, ptr(out), ldy, imy, float(alpha), *zargs,
-                                ptr(bias), int(bool(relu)), ptr(mask), f, stream_ptr(X.device)))
+        plan, n_long, n_chunks, chunk = self.plan()
+        scratch = None
+        if n_long > 0:
+            scratch = torch.empty(n_chunks * 2 * f, dtype=torch.float32, device=X.device)
+        check(_lib.lib.mh_cspmm_planned(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), self.n_rows,
+                                        ptr(X), ldx, imx, ptr(out), ldy, imy, float(alpha), *zargs,
+                                        ptr(bias), int(bool(relu)), ptr(mask), f,
+                                        ptr(plan), n_long, n_chunks, chunk, ptr(scratch),
+                                        0 if scratch is None else scratch.numel() * 4, stream_ptr(X.device)))
         if obs is not None:
             ev1.record(torch.cuda.current_stream(X.device))
             obs(ev0, ev1, dict(nnz=self.nnz, n_rows=self.n_rows, F=f, n_addends=int(z1 is not None) + int(z2 is not None)))
