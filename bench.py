@@ -10,9 +10,11 @@ Workload (BASELINE.json config 5, the one the metric's roofline target is quoted
 288 GB GPU): N = 10M nodes, E = 200M edges (src = floor(N u1^2), dst = floor(N u2^2), Philox seed
 43), 256 complex features, K = 3, q = 0.25.  One step = one MagNetConv forward: K fused complex
 SpMM orders + (K+1) real weight GEMMs + bias, inputs resident in HBM.  value = nnz(L) * K / t.
-With --gpus N > 1 the same graph is row-partitioned over the ranks (strong scaling): every rank
-owns a contiguous block of rows balanced by nonzeros, and each order exchanges the freshly
-computed row blocks over RCCL so that every rank again holds all rows it gathers from.
+With --gpus N > 1 the same graph is spread over the ranks (strong scaling), see magnet_amd/dist.py:
+--strategy rows: every rank owns a contiguous block of rows balanced by nonzeros and each order
+exchanges the freshly computed row blocks over RCCL; --strategy cols: every rank holds the whole
+Laplacian and a slice of the feature columns, the recursion runs without communication and one
+all-to-all per conv regroups the orders by rows for the weight GEMM; auto picks cols for K >= 2.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,6 +44,9 @@ def parse_args():
     p.add_argument('--K', type=int, default=3)
     p.add_argument('--q', type=float, default=0.25)
     p.add_argument('--seed', type=int, default=43)
+    p.add_argument('--strategy', choices=['auto', 'rows', 'cols'], default='auto',
+                   help='multi-GPU decomposition (see magnet_amd/dist.py)')
+    p.add_argument('--force-dist', action='store_true', help='take the multi-GPU code path even with one rank (rehearsal)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-sample-nodes', type=int, default=500_000)
     p.add_argument('--cpu-sample-edges', type=int, default=10_000_000)
@@ -113,7 +118,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         dist.init_process_group('nccl', device_id=dev)
 
     from magnet_amd import laplacian as lapmod
@@ -133,10 +139,19 @@ def main():
     torch.cuda.empty_cache()
 
     torch.manual_seed(1)
-    if world > 1:
-        from magnet_amd.dist import RowPartitionedConv
-        layer = RowPartitionedConv(lap, f, f, K, rank, world, dev)
-        del lap
+    strategy = 'single'
+    if multi:
+        from magnet_amd.dist import RowPartitionedConv, ColumnShardedConv
+        strategy = args.strategy
+        if strategy == 'auto':
+            # K <= 1 needs no exchange in the row partition; otherwise a graph without locality moves
+            # (K-1)*world/(K+1) times fewer bytes when feature columns are sharded instead
+            strategy = 'cols' if (K >= 2 and f % (4 * world) == 0) else 'rows'
+        if strategy == 'cols':
+            layer = ColumnShardedConv(lap, f, f, K, rank, world, dev)
+        else:
+            layer = RowPartitionedConv(lap, f, f, K, rank, world, dev)
+            del lap
         torch.cuda.empty_cache()
         step = layer.step
         launches = layer.launches
@@ -156,18 +171,18 @@ def main():
         step()
     launches.clear()
     lapmod.SPMM_OBSERVER = observer
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     lapmod.SPMM_OBSERVER = None
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -196,7 +211,7 @@ def main():
             'config': {
                 'workload': 'power-law digraph N=%d E=%d (seed %d), %d complex features, K=%d, q=%g; step = one '
                             'MagNetConv forward (K fused complex SpMM orders + K+1 weight GEMMs + bias)' % (n, e, args.seed, f, K, args.q),
-                'nnz': nnz_total, 'parallelism': 'rows%d' % world if world > 1 else 'single',
+                'nnz': nnz_total, 'parallelism': '%s%d' % (strategy, world) if multi else 'single',
             },
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -211,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

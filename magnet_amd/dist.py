@@ -1,10 +1,18 @@
-"""Row-partitioned propagation over the GPUs of one node (one process per GPU, torch.distributed:
-backend "nccl" = RCCL over xGMI on MI355X, "gloo" for CPU rehearsal of the exchange logic).
+"""Propagation over the GPUs of one node (one process per GPU, torch.distributed: backend "nccl" =
+RCCL over xGMI on MI355X, "gloo" for CPU rehearsal of the exchange logic).
 
 The reference is single-device (src/sparse_Magnet.py:23-24); this module is the graph-scale
-extension of its propagation (src/layer/sparse_magnet.py:50-72).
+extension of its propagation (src/layer/sparse_magnet.py:50-72).  Two decompositions:
 
-Decomposition
+* RowPartition  — rows of the Laplacian and of the features are cut into blocks; every order
+  exchanges the freshly computed blocks (the halo of a graph without locality is every row).
+  No communication at all for K = 1, and the natural choice when a partition keeps most
+  neighbours local.
+* ColumnSharded — every rank holds the whole Laplacian and a slice of the feature columns; the
+  recursion needs no communication and one all-to-all per layer turns column slices into row
+  blocks for the weight GEMM.  (K-1)*world/(K+1) times fewer bytes on a graph without locality.
+
+Row partition
 -------------
 * Rows of the Laplacian (and of every feature matrix) are cut into `world` contiguous blocks
   balanced by work (nonzeros + rows).  Rank p computes rows [b_p, b_{p+1}) of each order.
@@ -168,3 +176,109 @@ class RowPartitionedConv:
         for k in range(1, self.K + 1):
             out.addmm_(blk(zs[k]), self.weight[k])
         return out.view(rows, 2, -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# feature-column sharding: no exchange inside the recursion
+# ---------------------------------------------------------------------------------------------
+def column_bounds(n_features, world, quantum=4):
+    """world+1 column boundaries, multiples of `quantum` where the width allows (the vector SpMM
+    path wants slices that are multiples of 4 floats)."""
+    if n_features % (quantum * world) == 0 or n_features >= quantum * world:
+        units = n_features // quantum
+        b = [quantum * (units * p // world) for p in range(world)] + [n_features]
+    else:
+        b = [n_features * p // world for p in range(world)] + [n_features]
+    return b
+
+
+def all_to_all_blocks(send, recv, rank, world, group=None):
+    """send[p] goes to rank p, recv[p] is filled by rank p (lists of contiguous tensors; entry `rank`
+    is ignored).  Batched point-to-point: one direct transfer per GPU pair on the xGMI mesh."""
+    ops = []
+    for step in range(1, world):
+        to, frm = (rank + step) % world, (rank - step) % world
+        if send[to].numel():
+            ops.append(dist.P2POp(dist.isend, send[to], to, group))
+        if recv[frm].numel():
+            ops.append(dist.P2POp(dist.irecv, recv[frm], frm, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+class ColumnSharded:
+    """Every rank holds the WHOLE Laplacian (4.8 GB at 400M nonzeros: cheap next to 288 GB) and a
+    slice of the feature columns.  The K propagation orders then need no communication at all:
+    column f of L X depends on column f of X only.  The per-order weight GEMM mixes columns, so
+    before it the orders are transposed from column slices to row blocks with ONE all-to-all
+    (each rank sends 1/world of what it holds to every peer).  Per conv that moves
+    (K+1) * N * 8F * (world-1)/world^2 bytes per rank, against (K-1) * N * 8F * (world-1)/world
+    for the row partition on a graph without locality — (K-1) * world / (K+1) times less."""
+
+    def __init__(self, operator, n, n_features, rank, world, group=None):
+        self.op, self.n, self.rank, self.world, self.group = operator, n, rank, world, group
+        self.cb = column_bounds(n_features, world)
+        self.c0, self.c1 = self.cb[rank], self.cb[rank + 1]
+        self.rb = [n * p // world for p in range(world)] + [n]         # output row blocks
+        self.r0, self.r1 = self.rb[rank], self.rb[rank + 1]
+
+    def cheb_terms(self, x_slice, n_terms):
+        zs = [x_slice]
+        for k in range(1, n_terms):
+            z = torch.empty_like(x_slice)
+            if k == 1:
+                self.op.spmm(zs[0], out=z)
+            else:
+                self.op.spmm(zs[k - 1], out=z, alpha=2.0, z1=zs[k - 2], beta1=-1.0)
+            zs.append(z)
+        return zs
+
+    def to_row_blocks(self, zs):
+        """[N, 2, fc] per order (my columns, all rows) -> list over source ranks p of
+        [rows_me, 2, n_terms, fc_p] (my rows, p's columns, all orders)."""
+        k1 = len(zs)
+        rows_me = self.r1 - self.r0
+        send, recv = [], []
+        for p in range(self.world):
+            send.append(torch.stack([z[self.rb[p]:self.rb[p + 1]] for z in zs], dim=2))
+            fcp = self.cb[p + 1] - self.cb[p]
+            recv.append(send[p] if p == self.rank else
+                        torch.empty((rows_me, 2, k1, fcp), dtype=zs[0].dtype, device=zs[0].device))
+        wait_all(all_to_all_blocks(send, recv, self.rank, self.world, self.group))
+        return recv
+
+    def conv(self, x_slice, weight, bias):
+        """Rows [r0, r1) of sum_k T_k X W_k + bias, given this rank's column slice of X."""
+        k1, _, cout = weight.shape
+        zs = self.cheb_terms(x_slice, k1)
+        parts = self.to_row_blocks(zs)
+        rows_me = self.r1 - self.r0
+        out = None
+        for p, blk in enumerate(parts):
+            fcp = self.cb[p + 1] - self.cb[p]
+            if fcp == 0:
+                continue
+            wp = weight[:, self.cb[p]:self.cb[p + 1], :].reshape(k1 * fcp, cout)
+            a = blk.reshape(rows_me * 2, k1 * fcp)
+            if out is None:
+                out = torch.addmm(bias, a, wp) if bias is not None else torch.mm(a, wp)
+            else:
+                out.addmm_(a, wp)
+        return out.view(rows_me, 2, cout)
+
+
+class ColumnShardedConv:
+    """bench.py's multi-GPU step in the column-sharded form (same interface as RowPartitionedConv)."""
+
+    def __init__(self, lap, in_c, out_c, K, rank, world, device, seed=1):
+        self.shard = ColumnSharded(lap, lap.n_rows, in_c, rank, world)
+        self.K = K
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        stdv = 1.0 / out_c ** 0.5
+        self.weight = ((torch.rand(K + 1, in_c, out_c, generator=g) * 2 - 1) * stdv).to(device)
+        self.bias = torch.zeros(1, out_c, device=device)
+        gen = torch.Generator(device=device).manual_seed(seed + 1000 * rank)
+        self.x = torch.randn(lap.n_rows, 2, self.shard.c1 - self.shard.c0, device=device, generator=gen)
+        self.launches = []
+
+    def step(self):
+        return self.shard.conv(self.x, self.weight, self.bias)

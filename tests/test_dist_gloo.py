@@ -61,6 +61,50 @@ def _worker(rank, world, port, n_terms, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_cols(rank, world, port, n_terms, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        L, rp, ci, val = _graph()
+        n, f, cout = L.shape[0], 10, 6
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(n, 2, f, generator=g)
+        W = torch.randn(n_terms, f, cout, generator=g); b = torch.randn(1, cout, generator=g)
+        sh = D.ColumnSharded(ScipyOperator(rp, ci, val, n), n, f, rank, world)
+        out = sh.conv(x[:, :, sh.c0:sh.c1].contiguous(), W, b)
+        torch.save({'rb': sh.rb, 'cb': sh.cb, 'out': out}, os.path.join(out_dir, 'c%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_column_sharded_conv_matches_single_process(world, tmp_path):
+    n_terms = 4
+    mp.spawn(_worker_cols, args=(world, _free_port(), n_terms, str(tmp_path)), nprocs=world, join=True)
+    L, rp, ci, val = _graph()
+    n, f, cout = L.shape[0], 10, 6
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 2, f, generator=g)
+    W = torch.randn(n_terms, f, cout, generator=g); b = torch.randn(1, cout, generator=g)
+    rr, ri = O.cheb_conv_recursion(L, W, b, x[:, 0, :], x[:, 1, :])
+    outs = [torch.load(os.path.join(str(tmp_path), 'c%d.pt' % r)) for r in range(world)]
+    assert outs[0]['cb'][0] == 0 and outs[0]['cb'][-1] == f and outs[0]['rb'][-1] == n
+    got = torch.cat([o['out'] for o in outs], dim=0)
+    scale = float(rr.abs().max())
+    assert float((got[:, 0, :] - rr).abs().max()) <= 1e-5 * scale
+    assert float((got[:, 1, :] - ri).abs().max()) <= 1e-5 * scale
+
+
+def test_column_bounds():
+    assert D.column_bounds(256, 8) == [32 * p for p in range(9)]
+    b = D.column_bounds(100, 8)
+    assert b[0] == 0 and b[-1] == 100 and all(x <= y for x, y in zip(b, b[1:])) and all(x % 4 == 0 for x in b[:-1])
+    b = D.column_bounds(5, 4)
+    assert b[0] == 0 and b[-1] == 5 and all(x <= y for x, y in zip(b, b[1:]))
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
     return p

@@ -539,3 +539,18 @@ def test_in_out_degree_and_cache_glue(tmp_path):
     assert np.array_equal(T2.indices, G.indices) and np.abs(T2.data - G.data).max() <= 1e-5 * np.abs(G.data).max()
     e2 = P.to_edge_dataset_sparse(0.1, d.edge_index, 2, 0, n, root=root)
     assert len(e2) == 3 and e2.laplacian.nnz == 14680
+
+
+def test_column_sharded_conv_single_rank_on_gpu():
+    _, lap, H, M, O = _mods()
+    from magnet_amd import dist as D
+    n, e, f = 20000, 400000, 64
+    src, dst = lap.powerlaw_edges(n, e, 21, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    layer = D.ColumnShardedConv(L, f, f, 3, 0, 1, torch.device(DEV))
+    out = layer.step()
+    conv = M.ChebConv(f, f, 3, H.cheb_poly_sparse(L, 3), None).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(layer.weight); conv.bias.copy_(layer.bias)
+        want = conv.forward_packed(layer.x)
+    assert float((out - want).abs().max()) <= 1e-5 * float(want.abs().max())
