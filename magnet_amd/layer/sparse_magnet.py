@@ -247,6 +247,84 @@ class _ComplexReluFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------
+# pair gather of the link-prediction head, written straight into the concatenated layout
+# ----------------------------------------------------------------------------
+class _PairPlan:
+    """Selection matrices of a pair list `index` [M, 2] as unit-valued CSRs for the SpMM kernel:
+    pick[s] (M x N, one entry per row) gathers node index[:, s]; scatter[s] (N x M, its transpose,
+    pairs listed in ascending order per node) adds pair gradients back per node without atomics."""
+
+    def __init__(self, index, n):
+        dev = index.device
+        m = index.size(0)
+        ones = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+        ones[:, 0] = 1.0
+        arange = torch.arange(m + 1, dtype=torch.int32, device=dev)
+        self.pick, self.scatter = [], []
+        for s in (0, 1):
+            nodes = index[:, s].long()
+            if m and (int(nodes.min()) < 0 or int(nodes.max()) >= n):
+                raise MagnetHipError('pair index out of range [0, %d)' % n)
+            self.pick.append(MagneticLaplacian(arange, nodes.to(torch.int32), ones, n))
+            order = torch.argsort(nodes, stable=True)
+            rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(torch.bincount(nodes, minlength=n), 0)
+            self.scatter.append(MagneticLaplacian(rp.to(torch.int32), order.to(torch.int32), ones, m))
+        self.m, self.n = m, n
+
+
+_PAIR_CACHE = {}
+
+
+def _pair_plan(index, n):
+    key = (index.data_ptr(), tuple(index.shape), index._version, n)
+    hit = _PAIR_CACHE.get(key)
+    if hit is not None and hit[0] is index:
+        return hit[1]
+    plan = _PairPlan(index, n)
+    if len(_PAIR_CACHE) > 16:
+        _PAIR_CACHE.clear()
+    _PAIR_CACHE[key] = (index, plan)
+    return plan
+
+
+def _pair_views(x, f):
+    """[M, 4F] = [re_i | re_j | im_i | im_j]  ->  the i-slot and the j-slot as row-planar [M, 2, F] views."""
+    m = x.size(0)
+    return (torch.as_strided(x, (m, 2, f), (4 * f, 2 * f, 1), x.storage_offset()),
+            torch.as_strided(x, (m, 2, f), (4 * f, 2 * f, 1), x.storage_offset() + f))
+
+
+class _PairGatherFn(torch.autograd.Function):
+    """cat(real[i], real[j], imag[i], imag[j]) of reference src/layer/sparse_magnet.py:159 from the
+    row-planar trunk output, in one pass per slot; backward is a per-node sum in fixed order."""
+
+    @staticmethod
+    def forward(ctx, p, index):
+        p = p.contiguous()
+        n, _, f = p.shape
+        plan = _pair_plan(index, n)
+        out = torch.empty((plan.m, 4 * f), dtype=torch.float32, device=p.device)
+        yi, yj = _pair_views(out, f)
+        if plan.m:
+            plan.pick[0].spmm(p, out=yi)
+            plan.pick[1].spmm(p, out=yj)
+        ctx.plan, ctx.f = plan, f
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, f = ctx.plan, ctx.f
+        g = g.contiguous()
+        dp = torch.zeros((plan.n, 2, f), dtype=torch.float32, device=g.device)
+        if plan.m:
+            gi, gj = _pair_views(g, f)
+            plan.scatter[0].spmm(gi, out=dp)
+            plan.scatter[1].spmm(gj, out=dp, z1=dp, beta1=1.0)
+        return dp, None
+
+
+# ----------------------------------------------------------------------------
 # Laplacian argument handling
 # ----------------------------------------------------------------------------
 _COO_CACHE = {}
@@ -420,8 +498,7 @@ class ChebNet_Edge(nn.Module):
 
     def forward(self, real, imag, index):
         p = _run_trunk(self.Chebs, real, imag)
-        real, imag = p[:, 0, :], p[:, 1, :]
-        x = torch.cat((real[index[:, 0]], real[index[:, 1]], imag[index[:, 0]], imag[index[:, 1]]), dim=-1)
+        x = _PairGatherFn.apply(p, index)              # == cat(real[i], real[j], imag[i], imag[j])
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
         x = self.linear(x)

@@ -30,3 +30,25 @@ def in_out_degree(edge_index, size, as_written=True):
 def acc(pred, label):
     """Fraction of correct predictions (reference src/Edge_sparseMagnet.py:55-60)."""
     return float((pred == label).sum().item()) / max(len(pred), 1)
+
+
+def link_prediction_evaluation(out_val, out_test, y_val, y_test):
+    """Accuracy (all classes), then accuracy / AUC / micro-F1 / macro-F1 on the pairs whose label
+    is 0 or 1, for validation and test (reference src/utils/edge_data.py:538-586; the metrics are
+    host-side sklearn calls there too).  Inputs are log-probabilities [M, 2 or 3] and labels [M]."""
+    from sklearn.metrics import accuracy_score, f1_score, roc_auc_score
+
+    def one(out, y):
+        out = torch.exp(out).detach().to('cpu').numpy()
+        y = y.detach().to('cpu').numpy()
+        acc_full = accuracy_score(np.argmax(out, axis=1), y)
+        out = out[y < 2, :2]
+        y = y[y < 2]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            prob = out[:, 0] / (out[:, 0] + out[:, 1])
+        prob = np.nan_to_num(prob, nan=0.5, posinf=0)
+        pred = np.argmax(out, axis=1)
+        return [acc_full, accuracy_score(pred, y), roc_auc_score(y, prob), f1_score(pred, y, average='micro'),
+                f1_score(pred, y, average='macro')]
+
+    return [one(out_val, y_val), one(out_test, y_test)]
