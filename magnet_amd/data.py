@@ -1,0 +1,121 @@
+"""Graph inputs for the drivers: plain attribute bags with the fields the reference's glue reads
+(edge_index [2,E], edge_weight, x, y, train/val/test masks [N,10]) — reference
+src/utils/preprocess.py:165-171 — from files that can be read without unpickling, and seeded
+synthetic generators for the configurations whose files the reference does not ship.
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+class GraphData:
+    """Attribute bag standing in for torch_geometric.data.Data on this path."""
+
+    def __init__(self, **kw):
+        self.edge_weight = None
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def random_splits(labels, n_splits=10, train_per_class=20, val_size=500, seed=0):
+    """[N, n_splits] boolean train / val / test masks: `train_per_class` nodes of every class,
+    `val_size` of the remaining nodes, the rest for testing (the scheme of the reference's
+    citation / synthetic splits, src/utils/Citation.py:56 and src/utils/generate_cyclic.py:154;
+    the draws themselves are this module's own seeded ones)."""
+    labels = np.asarray(labels)
+    n = len(labels)
+    tr = np.zeros((n, n_splits), bool); va = np.zeros((n, n_splits), bool); te = np.zeros((n, n_splits), bool)
+    for s in range(n_splits):
+        rng = np.random.default_rng(seed * 1000 + s)
+        chosen = []
+        for c in np.unique(labels):
+            idx = np.nonzero(labels == c)[0]
+            chosen.append(rng.choice(idx, size=min(train_per_class, len(idx)), replace=False))
+        chosen = np.concatenate(chosen)
+        tr[chosen, s] = True
+        rest = rng.permutation(np.setdiff1d(np.arange(n), chosen))
+        v = rest[:min(val_size, len(rest))]
+        va[v, s] = True
+        te[rest[len(v):], s] = True
+    return torch.from_numpy(tr), torch.from_numpy(va), torch.from_numpy(te)
+
+
+def dsbm_cyclic(n_per_cluster=500, clusters=5, p_in=0.1, p_inter=0.1, p_q=0.95, seed=10, train_per_class=50):
+    """Cyclic directed stochastic block model (the model of reference
+    src/utils/generate_cyclic.py:79-143 with cycle=True, 279-290): undirected SBM edges with
+    probability p_in inside a cluster and p_inter between clusters that are adjacent on the cycle
+    0 -> 1 -> ... -> c-1 -> 0; inside a cluster an edge gets a uniformly random direction, between
+    adjacent clusters it points along the cycle with probability p_q.  Features are N(0,1) [N,1]
+    (generate_cyclic.py:178-179).  Seeded with numpy's default_rng."""
+    rng = np.random.default_rng(seed)
+    n = n_per_cluster * clusters
+    src, dst = [], []
+    for a in range(clusters):
+        # inside cluster a
+        iu = np.triu(rng.random((n_per_cluster, n_per_cluster)) < p_in, 1)
+        x, y = np.nonzero(iu)
+        flip = rng.random(len(x)) < 0.5
+        s = np.where(flip, y, x) + a * n_per_cluster; d = np.where(flip, x, y) + a * n_per_cluster
+        src.append(s); dst.append(d)
+        # between a and its successor on the cycle
+        b = (a + 1) % clusters
+        if clusters > 1 and not (clusters == 2 and a == 1):
+            x, y = np.nonzero(rng.random((n_per_cluster, n_per_cluster)) < p_inter)
+            fwd = rng.random(len(x)) < p_q
+            s = np.where(fwd, x + a * n_per_cluster, y + b * n_per_cluster)
+            d = np.where(fwd, y + b * n_per_cluster, x + a * n_per_cluster)
+            src.append(s); dst.append(d)
+    edge_index = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
+    y = np.repeat(np.arange(clusters), n_per_cluster)
+    x = torch.from_numpy(rng.normal(0, 1.0, (n, 1)).astype(np.float32))
+    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500, seed=seed)
+    return GraphData(x=x, edge_index=edge_index, edge_weight=None, y=torch.from_numpy(y).long(),
+                     train_mask=tr, val_mask=va, test_mask=te)
+
+
+def load_npz_citation(path, n_splits=10):
+    """`.npz` citation graphs (cora_ml, citeseer_npz; reference src/utils/Citation.py:36-73,96-110):
+    adjacency, dense features, labels, 20-per-class / 500 / rest splits.  allow_pickle stays off."""
+    if os.path.isdir(path):
+        path = os.path.join(path, os.path.basename(os.path.normpath(path)) + '.npz')
+    z = np.load(path, allow_pickle=False)
+    A = sp.csr_matrix((z['adj_data'], z['adj_indices'], z['adj_indptr']), shape=tuple(z['adj_shape'])).tocoo()
+    X = sp.csr_matrix((z['attr_data'], z['attr_indices'], z['attr_indptr']), shape=tuple(z['attr_shape']))
+    labels = z['labels'].astype(np.int64)
+    tr, va, te = random_splits(labels, n_splits, 20, 500, seed=0)
+    return GraphData(x=torch.from_numpy(np.asarray(X.todense())).float(),
+                     edge_index=torch.from_numpy(np.vstack([A.row, A.col]).astype(np.int64)), edge_weight=None,
+                     y=torch.from_numpy(labels), train_mask=tr, val_mask=va, test_mask=te)
+
+
+def load_telegram(folder, n_splits=10):
+    """telegram_adj.npz (weighted adjacency) + telegram_labels.npy, the inputs of reference
+    src/utils/telegram_prepare.py; features N(0,1) [N,1]; 60/20/20 random splits."""
+    A = sp.load_npz(os.path.join(folder, 'telegram_adj.npz')).tocoo()
+    labels = np.load(os.path.join(folder, 'telegram_labels.npy'), allow_pickle=False).astype(np.int64).ravel()
+    n = A.shape[0]
+    rng = np.random.default_rng(0)
+    tr = np.zeros((n, n_splits), bool); va = np.zeros((n, n_splits), bool); te = np.zeros((n, n_splits), bool)
+    for s in range(n_splits):
+        perm = np.random.default_rng(s).permutation(n)
+        a, b = int(0.6 * n), int(0.8 * n)
+        tr[perm[:a], s] = True; va[perm[a:b], s] = True; te[perm[b:], s] = True
+    return GraphData(x=torch.from_numpy(rng.normal(0, 1, (n, 1)).astype(np.float32)),
+                     edge_index=torch.from_numpy(np.vstack([A.row, A.col]).astype(np.int64)),
+                     edge_weight=A.data.astype(np.int64), y=torch.from_numpy(labels),
+                     train_mask=torch.from_numpy(tr), val_mask=torch.from_numpy(va), test_mask=torch.from_numpy(te))
+
+
+def load_edge_csv(edges_path, labels_path=None):
+    """`i,j,w` edge list with 1-based ids (dataset/cora/cora.edges) and optional `i,label` file."""
+    e = np.loadtxt(edges_path, delimiter=',', dtype=np.int64)
+    edge_index = torch.from_numpy((e[:, :2] - 1).T.copy())
+    n = int(edge_index.max()) + 1
+    y = None
+    if labels_path is not None:
+        l = np.loadtxt(labels_path, delimiter=',', dtype=np.int64)
+        y = np.zeros(n, np.int64); y[l[:, 0] - 1] = l[:, 1]
+        y = torch.from_numpy(y - y.min())
+    return GraphData(edge_index=edge_index, edge_weight=None, y=y, x=None)
