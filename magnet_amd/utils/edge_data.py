@@ -1,4 +1,6 @@
 """Link-prediction helpers on the hot path's edge (reference src/utils/edge_data.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -52,3 +54,123 @@ def link_prediction_evaluation(out_val, out_test, y_val, y_test):
                 f1_score(pred, y, average='macro')]
 
     return [one(out_val, y_val), one(out_test, y_test)]
+
+
+# ---------------------------------------------------------------------------------------------
+# link splits (reference src/utils/edge_data.py:122-265).  The reference delegates the edge
+# removal / negative sampling to stellargraph's EdgeSplitter, which is not installable here; the
+# procedure below restates what that call is documented to do ("global" method) with numpy's
+# seeded generator, and keeps the reference's labelling rule and output dictionary layout.
+# ---------------------------------------------------------------------------------------------
+def _split_undirected(und, n, p, seed, keep_connected):
+    """Remove int(p * |edges|) undirected edges (never an edge of a spanning forest when
+    keep_connected) and draw as many node pairs that are not adjacent.  und: [U, 2] with a < b.
+    Returns (remaining edges [U', 2], sampled pairs [2k, 2] = removed edges then non-edges)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import minimum_spanning_tree
+    rng = np.random.default_rng(seed)
+    u = len(und)
+    k = int(p * u)
+    removable = np.ones(u, bool)
+    if keep_connected and u:
+        g = sp.coo_matrix((np.ones(u), (und[:, 0], und[:, 1])), shape=(n, n)).tocsr()
+        t = minimum_spanning_tree(g).tocoo()
+        tree = set(zip(np.minimum(t.row, t.col).tolist(), np.maximum(t.row, t.col).tolist()))
+        removable = np.array([(a, b) not in tree for a, b in und.tolist()], bool)
+    cand = np.nonzero(removable)[0]
+    k = min(k, len(cand))
+    gone = rng.choice(cand, size=k, replace=False) if k else np.zeros(0, np.int64)
+    keep = np.ones(u, bool); keep[gone] = False
+    present = set(map(tuple, und.tolist()))
+    neg = []
+    seen = set()
+    while len(neg) < k:
+        a = rng.integers(0, n, size=2 * (k - len(neg)) + 8); b = rng.integers(0, n, size=len(a))
+        for x, y in zip(a.tolist(), b.tolist()):
+            if x == y:
+                continue
+            key = (min(x, y), max(x, y))
+            if key in present or key in seen:
+                continue
+            seen.add(key); neg.append((x, y))
+            if len(neg) == k:
+                break
+    pairs = np.concatenate([und[gone], np.array(neg, np.int64).reshape(-1, 2)]) if k else np.zeros((0, 2), np.int64)
+    return und[keep], pairs
+
+
+def undirected_label2directed_label(adj, edge_pairs, task):
+    """Orientation labels of sampled pairs (reference :122-161): a pair joined by a one-way edge is
+    labelled alternately 0 (listed along the edge) and 1 (listed against it), reciprocal pairs are
+    dropped, absent pairs get 2; for the existence tasks (task != 2) absent pairs become class 1
+    and class 1 is thinned to the size of class 0 with default_rng(1000)."""
+    labels = np.zeros(len(edge_pairs), dtype=np.int32)
+    new_edge_pairs = np.array(edge_pairs).copy()
+    counter = 0
+    for i, e in enumerate(edge_pairs):
+        fwd, bwd = adj[e[0], e[1]] > 0, adj[e[1], e[0]] > 0
+        if fwd or bwd:
+            if fwd and bwd:
+                labels[i] = -1
+                continue
+            along = [e[0], e[1]] if fwd else [e[1], e[0]]
+            if counter % 2 == 0:
+                labels[i] = 0; new_edge_pairs[i] = along
+            else:
+                labels[i] = 1; new_edge_pairs[i] = along[::-1]
+            counter += 1
+        else:
+            labels[i] = 2
+    if task != 2:
+        labels[labels == 2] = 1
+        neg = np.where(labels == 1)[0]
+        rng = np.random.default_rng(1000)
+        neg_half = rng.choice(neg, size=max(len(neg) - int(np.sum(labels == 0)), 0), replace=False)
+        labels[neg_half] = -1
+    return new_edge_pairs[labels >= 0], labels[labels >= 0]
+
+
+def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15, 0.05), task=2, label_dim=2):
+    """{split: {'graph': LongTensor [2, E_obs], 'undirected': ndarray, 'train' | 'validate' | 'test':
+    {'pairs': int [M, 2], 'label': int32 [M]}}} — the layout of reference :221-239; cached under the
+    reference's file name (a cache written by this function is a pickle of this process's own data)."""
+    import pickle as pk
+    import scipy.sparse as sp
+    save_file = save_path + 'task' + str(task) + 'dim' + str(label_dim) + 'prob' + str(int(probs[0] * 100)) + '_' + \
+        str(int(probs[1] * 100)) + '.pk'
+    if os.path.exists(save_file) and os.path.exists(save_file + '.magnet_amd'):
+        with open(save_file, 'rb') as f:
+            return pk.load(f)
+    ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
+    A = sp.coo_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(size, size), dtype=np.float32).tocsr()
+    S = (A + A.T).tocoo()
+    und = np.stack([S.row, S.col], 1)
+    und = und[und[:, 0] < und[:, 1]].astype(np.int64)
+    out = {}
+    for ind in range(splits):
+        g_test, ids_test = _split_undirected(und, size, float(probs[0]), ind, True)
+        ids_test, labels_test = undirected_label2directed_label(A, ids_test, task)
+        g_val, ids_val = _split_undirected(g_test, size, float(probs[1]), ind, True)
+        ids_val, labels_val = undirected_label2directed_label(A, ids_val, task)
+        _, ids_train = _split_undirected(g_val, size, 0.99, ind, False)
+        ids_train, labels_train = undirected_label2directed_label(A, ids_train, task)
+        observed = np.zeros((len(g_val), 2), dtype=np.int32)
+        for i, (a, b) in enumerate(g_val.tolist()):        # back to the stored direction (reference :197-203)
+            if A[a, b] > 0:
+                observed[i] = [a, b]
+            if A[b, a] > 0:
+                observed[i] = [b, a]
+        if label_dim == 2:
+            ids_train, labels_train = ids_train[labels_train < 2], labels_train[labels_train < 2]
+            ids_test, labels_test = ids_test[labels_test < 2], labels_test[labels_test < 2]
+            ids_val, labels_val = ids_val[labels_val < 2], labels_val[labels_val < 2]
+        out[ind] = {'graph': torch.from_numpy(observed.T.copy()).long(),
+                    'undirected': np.concatenate([und[:, ::-1], und]).astype(np.int32),
+                    'train': {'pairs': ids_train, 'label': labels_train},
+                    'validate': {'pairs': ids_val, 'label': labels_val},
+                    'test': {'pairs': ids_test, 'label': labels_test}}
+    os.makedirs(os.path.dirname(save_file) or '.', exist_ok=True)
+    with open(save_file, 'wb') as f:
+        pk.dump(out, f, protocol=pk.HIGHEST_PROTOCOL)
+    open(save_file + '.magnet_amd', 'w').write('written by magnet_amd.utils.edge_data.generate_dataset_3class\n')
+    return out

@@ -566,3 +566,35 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (1, 4) and res[0, 1] >= 0.9, res
     res = drv.run(['-D', '--dataset', 'syn/cyclic', '--q', '0.1', '--K', '1', '--splits', '1', '--log_root', str(tmp_path) + '/'])
     assert res.shape == (1, 4)
+
+
+def test_link_driver_runs_all_tasks(tmp_path):
+    """Reference smoke criterion (execution/setup_test.sh:11,15: `-D` runs must not crash) plus a short
+    real run: direction prediction on a cyclic DSBM is learnable from degree features + MagNet."""
+    from magnet_amd import Edge_sparseMagnet as drv
+    root = str(tmp_path) + '/'
+    for task, ncls in ((1, 2), (2, 3), (3, 2)):
+        res = drv.run(['-D', '--dataset', 'syn/cyclic', '--task', str(task), '--num_class_link', str(ncls), '--q', '0.1',
+                       '--K', '2', '-a', '--num_filter', '8', '--splits', '1', '--log_root', root, '--data_path', root])
+        assert res.shape[0] == 1 and np.isfinite(res).all()
+    # a real run on the CiteSeer graph of the golden fixture: direction task, true degree features
+    _, lap, H, M, O = _mods()
+    from magnet_amd.utils.edge_data import generate_dataset_3class, in_out_degree
+    from magnet_amd.utils.preprocess import to_edge_dataset_sparse
+    from magnet_amd.train import link_epoch
+    g = load_golden('citeseer_link_case.npz')
+    n = int(g['n'])
+    ei = torch.from_numpy(np.vstack([g['row'], g['col']]))
+    ds = generate_dataset_3class(ei, n, root + 'cs/', splits=1, task=1, label_dim=2)[0]
+    L = to_edge_dataset_sparse(0.1, ds['graph'], 2, 0, n, root=root)
+    X = in_out_degree(ds['graph'], n, as_written=False).to(DEV)
+    torch.manual_seed(0)
+    net = M.ChebNet_Edge(2, L, None, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
+    t = lambda a: torch.from_numpy(np.asarray(a)).long().to(DEV)
+    losses = []
+    for _ in range(80):
+        tl, ta, vl, va = link_epoch(net, opt, X, X, t(ds['train']['pairs']), t(ds['train']['label']),
+                                    t(ds['validate']['pairs']), t(ds['validate']['label']))
+        losses.append(tl.item())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.02, (losses[0], losses[-1])

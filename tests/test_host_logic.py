@@ -55,3 +55,38 @@ def test_cache_reader_round_trip(tmp_path):
             return (os.system, ('echo should-never-run > %s' % (tmp_path / 'pwned'),))
     node = load_inert(pickle.dumps({'L': [Evil()]}))
     assert isinstance(node['L'][0], Inert) and not (tmp_path / 'pwned').exists()
+
+
+def test_link_split_generation(tmp_path):
+    from magnet_amd.utils.edge_data import generate_dataset_3class, undirected_label2directed_label
+    from magnet_amd.data import dsbm_cyclic
+    import scipy.sparse as sp
+    d = dsbm_cyclic(n_per_cluster=40, clusters=3, seed=1)
+    n = 120
+    ds = generate_dataset_3class(d.edge_index, n, str(tmp_path) + '/x', splits=2, probs=[0.15, 0.05], task=2, label_dim=3)
+    A = sp.coo_matrix((np.ones(d.edge_index.size(1)), (d.edge_index[0].numpy(), d.edge_index[1].numpy())), shape=(n, n)).tocsr()
+    for s in (0, 1):
+        g = ds[s]['graph']
+        assert g.dtype == torch.int64 and g.size(0) == 2
+        assert all(A[int(a), int(b)] > 0 for a, b in g.t().tolist())                  # observed edges are real edges
+        obs = set(map(tuple, g.t().tolist()))
+        for part in ('train', 'validate', 'test'):
+            pairs, lab = ds[s][part]['pairs'], ds[s][part]['label']
+            assert len(pairs) == len(lab) and set(np.unique(lab)) <= {0, 1, 2}
+            for (a, b), l in zip(pairs.tolist(), lab.tolist()):
+                if l == 0:
+                    assert A[a, b] > 0 and A[b, a] == 0
+                elif l == 1:
+                    assert A[b, a] > 0 and A[a, b] == 0
+                else:
+                    assert A[a, b] == 0 and A[b, a] == 0
+        # held-out positive pairs are not in the observed graph
+        for part in ('validate', 'test'):
+            for (a, b), l in zip(ds[s][part]['pairs'].tolist(), ds[s][part]['label'].tolist()):
+                if l < 2:
+                    assert (a, b) not in obs and (b, a) not in obs
+    again = generate_dataset_3class(d.edge_index, n, str(tmp_path) + '/x', splits=2, probs=[0.15, 0.05], task=2, label_dim=3)
+    assert torch.equal(again[0]['graph'], ds[0]['graph'])                              # cached
+    # existence task: two balanced classes
+    p, l = undirected_label2directed_label(A, ds[0]['test']['pairs'], task=1)
+    assert set(np.unique(l)) <= {0, 1} and abs(int((l == 0).sum()) - int((l == 1).sum())) <= 1
