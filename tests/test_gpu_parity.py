@@ -598,3 +598,29 @@ def test_link_driver_runs_all_tasks(tmp_path):
                                     t(ds['validate']['pairs']), t(ds['validate']['label']))
         losses.append(tl.item())
     assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.02, (losses[0], losses[-1])
+
+
+def test_hip_graph_epoch_replay_matches_eager():
+    """The epoch captured as one HIP graph (train step + Adam + eval forward) gives the eager numbers."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd.train import node_epoch, GraphedEpoch
+    from magnet_amd.data import dsbm_cyclic
+    g = dsbm_cyclic(n_per_cluster=100, clusters=5, seed=2)
+    n = g.x.size(0)
+    L = H.hermitian_decomp_sparse_device(g.edge_index[0], g.edge_index[1], n, 0.1)
+    X = g.x.to(DEV); y = g.y[None].to(DEV)
+    tr = g.train_mask[:, 0].nonzero().squeeze(1).to(DEV); va = g.val_mask[:, 0].nonzero().squeeze(1).to(DEV)
+
+    def make():
+        torch.manual_seed(5)
+        net = M.ChebNet(1, H.cheb_poly_sparse(L, 2), None, num_filter=16, K=2, label_dim=5, activation=True, layer=2).to(DEV)
+        return net, torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True)
+    net_e, opt_e = make()
+    eager = [[t.item() for t in node_epoch(net_e, opt_e, X, X, y, tr, va)] for _ in range(8)]
+    net_g, opt_g = make()
+    ge = GraphedEpoch(lambda: node_epoch(net_g, opt_g, X, X, y, tr, va), warmup=3)      # 3 eager warm-up epochs; capture runs nothing
+    replay = [[t.item() for t in ge()] for _ in range(5)]
+    for a, b in zip(eager[3:], replay):
+        assert_close(np.array(b), np.array(a), rel=1e-4, what='graph replay vs eager')
+    for pe, pg in zip(net_e.parameters(), net_g.parameters()):
+        assert_close(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rel=1e-4)
