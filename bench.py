@@ -48,8 +48,8 @@ def parse_args():
                    help='multi-GPU decomposition (see magnet_amd/dist.py)')
     p.add_argument('--force-dist', action='store_true', help='take the multi-GPU code path even with one rank (rehearsal)')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-sample-nodes', type=int, default=500_000)
-    p.add_argument('--cpu-sample-edges', type=int, default=10_000_000)
+    p.add_argument('--cpu-sample-nodes', type=int, default=250_000)
+    p.add_argument('--cpu-sample-edges', type=int, default=5_000_000)
     return p.parse_args()
 
 

@@ -62,6 +62,17 @@ struct SpmmArgs {
 };
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// gathered feature rows: read once per nonzero with no reuse worth caching at graph scale
+template <bool NT>
+__device__ inline float4 ldx4(const float* p) {
+    if constexpr (NT) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ inline void cfma(float4& are, float4& aim, float2 v, float4 xr, float4 xi) {
@@ -103,7 +114,7 @@ struct Lanes {
 
 // sum_j val[j] * X[col[j]] over nonzeros [start, end) of one row, into per-lane accumulators;
 // afterwards every lane of group 0 holds the sum over all groups.
-template <int LPN, int CH, int UNROLL>
+template <int LPN, int CH, int UNROLL, bool NT>
 __device__ inline void accumulate(const SpmmArgs& a, const Lanes<LPN, CH>& L, int start, int end, float4 (&are)[CH],
                                   float4 (&aim)[CH]) {
     constexpr int G = 64 / LPN;
@@ -126,8 +137,8 @@ __device__ inline void accumulate(const SpmmArgs& a, const Lanes<LPN, CH>& L, in
             const float* xrow = a.X + int64_t(cidx[u]) * a.ldx;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                xr[u][c] = ld4(xrow + L.foff[c]);
-                xi[u][c] = ld4(xrow + a.imx + L.foff[c]);
+                xr[u][c] = ldx4<NT>(xrow + L.foff[c]);
+                xi[u][c] = ldx4<NT>(xrow + a.imx + L.foff[c]);
             }
         }
 #pragma unroll
@@ -146,8 +157,8 @@ __device__ inline void accumulate(const SpmmArgs& a, const Lanes<LPN, CH>& L, in
         const float* xrow = a.X + int64_t(cj) * a.ldx;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            float4 xr = ld4(xrow + L.foff[c]);
-            float4 xi = ld4(xrow + a.imx + L.foff[c]);
+            float4 xr = ldx4<NT>(xrow + L.foff[c]);
+            float4 xi = ldx4<NT>(xrow + a.imx + L.foff[c]);
             cfma(are[c], aim[c], v, xr, xi);
         }
     }
@@ -194,7 +205,7 @@ __device__ inline void epilogue(const SpmmArgs& a, int r, int64_t foff, float4 a
 }
 
 // one wave per row (rows dealt round-robin over the grid's waves); rows in the plan are skipped
-template <int LPN, int CH, int UNROLL>
+template <int LPN, int CH, int UNROLL, bool NT>
 __global__ void __launch_bounds__(kBlock) cspmm_vec4(const SpmmArgs a) {
     const Lanes<LPN, CH> L(a.F);
     const int wave0 = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
@@ -203,7 +214,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_vec4(const SpmmArgs a) {
         const int start = a.row_ptr[r], end = a.row_ptr[r + 1];
         if (a.n_long > 0 && end - start > a.long_threshold) continue;
         float4 are[CH], aim[CH];
-        accumulate<LPN, CH, UNROLL>(a, L, start, end, are, aim);
+        accumulate<LPN, CH, UNROLL, NT>(a, L, start, end, are, aim);
         if (L.g == 0) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_vec4(const SpmmArgs a) {
 }
 
 // one wave per chunk of a long row: raw partial sums to scratch[chunk][2][F]
-template <int LPN, int CH, int UNROLL>
+template <int LPN, int CH, int UNROLL, bool NT>
 __global__ void __launch_bounds__(kBlock) cspmm_vec4_chunks(const SpmmArgs a) {
     const Lanes<LPN, CH> L(a.F);
     const int c0 = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_vec4_chunks(const SpmmArgs a) {
     const int row_end = a.row_ptr[r + 1];
     const int end = start + a.chunk < row_end ? start + a.chunk : row_end;
     float4 are[CH], aim[CH];
-    accumulate<LPN, CH, UNROLL>(a, L, start, end, are, aim);
+    accumulate<LPN, CH, UNROLL, NT>(a, L, start, end, are, aim);
     if (L.g == 0) {
         float* p = a.scratch + int64_t(c0) * 2 * a.F;
 #pragma unroll
@@ -349,13 +360,29 @@ unsigned spmm_grid(int32_t n_rows) {
     return unsigned((cap == 0 || want < cap) ? want : cap);
 }
 
+bool use_nt(const SpmmArgs& a) {
+    static int mode = -1;                           // tuning knob: MH_SPMM_NT = 0 | 1 | auto (default)
+    if (mode < 0) {
+        const char* e = getenv("MH_SPMM_NT");
+        mode = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
+    }
+    if (mode != 2) return mode == 1;
+    // feature matrix far larger than the 256 MiB Infinity Cache: gathered rows are not worth caching
+    return false;
+}
+
 template <int LPN, int CH, int UNROLL>
 void launch_vec(const SpmmArgs& a, hipStream_t s) {
-    cspmm_vec4<LPN, CH, UNROLL><<<spmm_grid(a.n_rows), kBlock, 0, s>>>(a);
-    if (a.n_long > 0) {
-        cspmm_vec4_chunks<LPN, CH, UNROLL><<<unsigned((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), kBlock, 0, s>>>(a);
-        cspmm_vec4_combine<<<unsigned((a.n_long + kWavesPerBlock - 1) / kWavesPerBlock), kBlock, 0, s>>>(a);
+    const unsigned g_chunks = unsigned((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (use_nt(a)) {
+        cspmm_vec4<LPN, CH, UNROLL, true><<<spmm_grid(a.n_rows), kBlock, 0, s>>>(a);
+        if (a.n_long > 0) cspmm_vec4_chunks<LPN, CH, UNROLL, true><<<g_chunks, kBlock, 0, s>>>(a);
+    } else {
+        cspmm_vec4<LPN, CH, UNROLL, false><<<spmm_grid(a.n_rows), kBlock, 0, s>>>(a);
+        if (a.n_long > 0) cspmm_vec4_chunks<LPN, CH, UNROLL, false><<<g_chunks, kBlock, 0, s>>>(a);
     }
+    if (a.n_long > 0)
+        cspmm_vec4_combine<<<unsigned((a.n_long + kWavesPerBlock - 1) / kWavesPerBlock), kBlock, 0, s>>>(a);
 }
 template <int LPN>
 void launch_scalar(const SpmmArgs& a, hipStream_t s) {

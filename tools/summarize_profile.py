@@ -6,7 +6,7 @@ per SpMM launch, which bench.py reports as roofline.traffic).
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950
 FETCH_SIZE reports half the bytes of 16-byte-per-lane coalesced reads (checked here on the
-bias/ReLU kernel, whose traffic is known exactly: it reads and writes every output byte once).
+builder's make_records kernel, whose traffic is known exactly: 8 bytes read and 16 written per edge).
 """
 import csv
 import glob
@@ -20,7 +20,8 @@ src = os.path.join(ROOT, 'gpurun_out', 'prof')
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w', newline='') as f:
     w = csv.writer(f)
@@ -36,10 +37,11 @@ with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w', newline='') as f:
 bench = json.loads(open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines()[-1])
 per = {}
 for kind in ('fetch', 'write'):
-    path = glob.glob(os.path.join(src, kind, '*', '*_counter_collection.csv'))[0]
+    path = newest(os.path.join(src, kind, '*', '*_counter_collection.csv'))
     for r in csv.DictReader(open(path)):
         n = r['Kernel_Name']
-        key = 'cspmm' if 'cspmm' in n else 'bias_relu' if 'bias_relu' in n else 'gemm' if n.startswith('Cijk_') else None
+        key = ('cspmm' if 'cspmm_vec4<' in n else 'cspmm_chunks' if 'cspmm_vec4_chunks' in n else 'cspmm_combine' if 'cspmm_vec4_combine' in n
+               else 'make_records' if 'make_records' in n else 'gemm' if n.startswith('Cijk_') else None)
         if key:
             per.setdefault((key, kind), []).append(
                 (float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
@@ -53,15 +55,20 @@ with open(os.path.join(dst, tag + '_hbm_counters.csv'), 'w', newline='') as f:
 mean = lambda xs: sum(xs) / len(xs)
 fetch = mean([v for v, _ in per[('cspmm', 'fetch')]]) * 1024 * 2
 write = mean([v for v, _ in per[('cspmm', 'write')]]) * 1024
-cal_f = mean([v for v, _ in per[('bias_relu', 'fetch')]]) * 1024 * 2
-cal_w = mean([v for v, _ in per[('bias_relu', 'write')]]) * 1024
+cal_f = mean([v for v, _ in per[('make_records', 'fetch')]]) * 1024 * 2
+cal_w = mean([v for v, _ in per[('make_records', 'write')]]) * 1024
+for extra in ('cspmm_chunks', 'cspmm_combine'):       # the hub-row kernels belong to the same SpMM order
+    if (extra, 'fetch') in per:
+        fetch += mean([v for v, _ in per[(extra, 'fetch')]]) * 1024 * 2
+        write += mean([v for v, _ in per[(extra, 'write')]]) * 1024
 nnz = bench['config']['nnz']
 import re
 m = re.search(r'N=(\d+) E=(\d+).*?, (\d+) complex features', bench['config']['workload'])
 out = {'nodes': int(m.group(1)), 'edges': int(m.group(2)), 'features': int(m.group(3)), 'nnz': nnz,
        'hbm_bytes_per_launch': fetch + write, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
        'algorithmic_bytes_per_launch': bench['roofline']['algorithmic_bytes_per_launch'],
-       'calibration': {'kernel': 'bias_relu_kernel', 'expected_bytes_each_way': int(m.group(1)) * 8 * int(m.group(3)),
+       'calibration': {'kernel': 'make_records (reads two int32 per edge, writes two 8-byte keys per edge)',
+                       'expected_read_bytes': int(m.group(2)) * 8, 'expected_write_bytes': int(m.group(2)) * 16,
                        'measured_read_corrected': cal_f, 'measured_write': cal_w},
        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s' % tag}
 json.dump(out, open(os.path.join(dst, 'spmm_traffic.json'), 'w'), indent=1)
