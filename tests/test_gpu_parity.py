@@ -624,3 +624,47 @@ def test_hip_graph_epoch_replay_matches_eager():
         assert_close(np.array(b), np.array(a), rel=1e-4, what='graph replay vs eager')
     for pe, pg in zip(net_e.parameters(), net_g.parameters()):
         assert_close(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rel=1e-4)
+
+
+def test_spmm_full_size_properties():
+    """Config-5 size (10M nodes / 200M edges / 256 complex features, ~70 GB): properties that need
+    no oracle run.  Bitwise determinism; exact homogeneity under a power-of-two scale; a real
+    Hermitian form; and 2000 sampled output rows recomputed in fp64 from the CSR with torch ops."""
+    _, lap, _, _, _ = _mods()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100e9:
+        pytest.skip('needs ~70 GB of free HBM')
+    n, e, f = 10_000_000, 200_000_000, 256
+    src, dst = lap.powerlaw_edges(n, e, 43, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    del src, dst
+    assert L.nnz % 2 == 0 and 0 < L.nnz <= 2 * e
+    plan, n_long, n_chunks, chunk = L.plan()
+    assert n_long > 0 and n_chunks >= n_long                  # hub rows exist at this size and take the chunk path
+    X = torch.randn(n, 2, f, device=DEV)
+    Y = L.spmm(X)
+    Y2 = L.spmm(X)
+    assert torch.equal(Y, Y2)
+    X.mul_(2.0)
+    L.spmm(X, out=Y2)
+    X.mul_(0.5)
+    Y2.mul_(0.5)
+    assert torch.equal(Y, Y2)                                 # L(2x)/2 == L(x) exactly in binary floating point
+    del Y2
+    form_im = (X[:, 0, :].double() * Y[:, 1, :].double() - X[:, 1, :].double() * Y[:, 0, :].double()).sum()
+    form_re = (X[:, 0, :].double() * Y[:, 0, :].double() + X[:, 1, :].double() * Y[:, 1, :].double()).sum()
+    assert abs(form_im.item()) <= 1e-6 * abs(form_re.item()) + 1.0
+    g = torch.Generator(device=DEV).manual_seed(7)
+    rows = torch.cat([torch.arange(0, 8, device=DEV), torch.randint(0, n, (2000,), device=DEV, generator=g)])
+    rp = L.row_ptr.long()
+    worst = 0.0
+    for r in rows.tolist():
+        a, b = int(rp[r]), int(rp[r + 1])
+        cols = L.col_idx[a:b].long()
+        v = L.val[a:b].double()
+        xr = X[cols, 0, :].double(); xi = X[cols, 1, :].double()
+        re = (v[:, 0:1] * xr - v[:, 1:2] * xi).sum(0); im = (v[:, 0:1] * xi + v[:, 1:2] * xr).sum(0)
+        scale = max(float(re.abs().max()), float(im.abs().max()), 1e-3)
+        worst = max(worst, float((Y[r, 0, :].double() - re).abs().max()) / scale,
+                    float((Y[r, 1, :].double() - im).abs().max()) / scale)
+    assert worst <= 1e-5, worst
