@@ -282,3 +282,135 @@ class ColumnShardedConv:
 
     def step(self):
         return self.shard.conv(self.x, self.weight, self.bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# training over several GPUs: ChebNet with the layers alternating between the two layouts
+# ---------------------------------------------------------------------------------------------
+def _regroup(x, src_bounds, dst_bounds, rank, world, group, to_cols):
+    """to_cols=True : x [rows_me, 2, k, C]  (my rows, all columns)  ->  [N, 2, k, fc_me]
+       to_cols=False: x [N, 2, k, fc_me]    (all rows, my columns)  ->  [rows_me, 2, k, C]
+    src_bounds / dst_bounds are (row bounds, column bounds)."""
+    rb, cb = src_bounds, dst_bounds
+    if to_cols:
+        send = [x[..., cb[p]:cb[p + 1]].contiguous() for p in range(world)]
+        recv = [send[p] if p == rank else
+                torch.empty((rb[p + 1] - rb[p],) + tuple(x.shape[1:-1]) + (cb[rank + 1] - cb[rank],), dtype=x.dtype, device=x.device)
+                for p in range(world)]
+        wait_all(all_to_all_blocks(send, recv, rank, world, group))
+        return torch.cat(recv, dim=0)
+    send = [x[rb[p]:rb[p + 1]].contiguous() for p in range(world)]
+    recv = [send[p] if p == rank else
+            torch.empty((rb[rank + 1] - rb[rank],) + tuple(x.shape[1:-1]) + (cb[p + 1] - cb[p],), dtype=x.dtype, device=x.device)
+            for p in range(world)]
+    wait_all(all_to_all_blocks(send, recv, rank, world, group))
+    return torch.cat(recv, dim=-1)
+
+
+class _RegroupFn(torch.autograd.Function):
+    """All-to-all between the row-block layout and the column-slice layout; its backward is the
+    opposite regrouping of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, rb, cb, rank, world, group, to_cols):
+        ctx.args = (rb, cb, rank, world, group, to_cols)
+        return _regroup(x, rb, cb, rank, world, group, to_cols)
+
+    @staticmethod
+    def backward(ctx, g):
+        rb, cb, rank, world, group, to_cols = ctx.args
+        return _regroup(g.contiguous(), rb, cb, rank, world, group, not to_cols), None, None, None, None, None, None
+
+
+class ShardedChebNet:
+    """Runs a ChebNet (magnet_amd.layer.sparse_magnet.ChebNet, same parameters / state_dict) on
+    `world` GPUs.  Every rank holds the whole Laplacian; node features enter as row blocks.  Layers
+    alternate between two forms so that each needs ONE all-to-all:
+      rows in  -> GEMM first: Y = X [W_0|..|W_K] on the local rows, regroup to column slices, Clenshaw
+                  recurrence on the slices (no communication), bias + complex ReLU fused -> columns out
+      cols in  -> SpMM first: T_k X on the column slices (no communication), regroup to row blocks,
+                  sum_k Z_k W_k + bias, complex ReLU -> rows out
+    The classification head is row-local.  Parameter gradients are summed over ranks (all-reduce);
+    the loss is the global mean over the training nodes."""
+
+    def __init__(self, net, operator, n, rank, world, group=None):
+        from .layer.sparse_magnet import ChebConv, complex_relu_layer
+        self.net, self.op, self.n, self.rank, self.world, self.group = net, operator, n, rank, world, group
+        self.rb = [n * p // world for p in range(world)] + [n]
+        self.r0, self.r1 = self.rb[rank], self.rb[rank + 1]
+        mods = list(net.Chebs)
+        self.layers = []
+        i = 0
+        while i < len(mods):
+            assert isinstance(mods[i], ChebConv)
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], complex_relu_layer)
+            self.layers.append((mods[i], relu))
+            i += 2 if relu else 1
+
+    def _regroup(self, x, cb, to_cols):
+        return _RegroupFn.apply(x, self.rb, cb, self.rank, self.world, self.group, to_cols)
+
+    def trunk(self, x_rows):
+        """x_rows: [rows_me, 2, C_in] row block of the packed input -> [rows_me, 2, F] row block."""
+        from .layer.sparse_magnet import _ChebTermsFn, _ClenshawFn, _ComplexReluFn
+        x, layout = x_rows, 'rows'
+        rows_me = self.r1 - self.r0
+        for conv, relu in self.layers:
+            w, b = conv.weight, conv.bias
+            k1, cin, cout = w.shape
+            if layout == 'rows':
+                y = torch.matmul(x.reshape(rows_me * 2, cin), w.permute(1, 0, 2).reshape(cin, k1 * cout))
+                cb = column_bounds(cout, self.world)
+                yc = self._regroup(y.view(rows_me, 2, k1, cout), cb, True)
+                bs = None if b is None else b.reshape(-1)[cb[self.rank]:cb[self.rank + 1]]
+                x = _ClenshawFn.apply(yc, bs, self.op, relu)
+                layout, cur_cb = 'cols', cb
+            else:
+                z = _ChebTermsFn.apply(x, self.op, k1)
+                r = self._regroup(z, cur_cb, False)
+                out = torch.matmul(r.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
+                if b is not None:
+                    out = out + b.reshape(1, 1, cout)
+                x = _ComplexReluFn.apply(out) if relu else out
+                layout = 'rows'
+        if layout == 'cols':
+            x = self._regroup(x.unsqueeze(2), cur_cb, False).squeeze(2)
+        return x
+
+    def forward(self, x_rows):
+        """-> log-probabilities [1, label_dim, rows_me] of the rank's nodes."""
+        import torch.nn.functional as F
+        p = self.trunk(x_rows)
+        x = p.reshape(p.size(0), -1)
+        if self.net.dropout > 0:
+            x = F.dropout(x, self.net.dropout, training=self.net.training)
+        x = F.linear(x, self.net.Conv.weight.squeeze(-1), self.net.Conv.bias)
+        return F.log_softmax(x.t().unsqueeze(0), dim=1)
+
+    def all_reduce_grads(self):
+        for p in self.net.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if self.world > 1:
+                dist.all_reduce(p.grad, group=self.group)
+
+    def epoch(self, opt, x_rows, label_rows, train_rows, val_rows, n_train, n_val):
+        """One epoch of the reference loop (src/sparse_Magnet.py:143-176) on this rank's rows:
+        label_rows [1, rows_me], train_rows / val_rows index tensors into the local rows,
+        n_train / n_val the GLOBAL numbers of training / validation nodes."""
+        import torch.nn.functional as F
+        self.net.train()
+        preds = self.forward(x_rows)
+        loss = F.nll_loss(preds[:, :, train_rows], label_rows[:, train_rows], reduction='sum') / n_train
+        opt.zero_grad()
+        loss.backward()
+        self.all_reduce_grads()
+        opt.step()
+        self.net.eval()
+        with torch.no_grad():
+            preds = self.forward(x_rows)
+            vloss = F.nll_loss(preds[:, :, val_rows], label_rows[:, val_rows], reduction='sum') / n_val
+        stats = torch.stack([loss.detach(), vloss])
+        if self.world > 1:
+            dist.all_reduce(stats, group=self.group)
+        return stats[0], stats[1]

@@ -137,8 +137,9 @@ class _ChebConvFn(torch.autograd.Function):
         w = weight.detach()
         gemm_first = cout < cin
         if gemm_first:
-            ycat = torch.mm(_rows2(xp), w.permute(1, 0, 2).reshape(cin, k1 * cout)).view(n, 2, k1, cout)
-            out, mask = _clenshaw(lap, [ycat[:, :, k, :] for k in range(k1)], None if bias is None else bias.detach(), relu)
+            # one contiguous [N, 2, C_out] matrix per order: the SpMM gathers whole feature rows
+            ys = [torch.mm(_rows2(xp), w[k]).view(n, 2, cout) for k in range(k1)]
+            out, mask = _clenshaw(lap, ys, None if bias is None else bias.detach(), relu)
             saved_z = None
         else:
             zs = _cheb_terms(lap, xp, k1)
@@ -188,6 +189,46 @@ class _ChebConvFn(torch.autograd.Function):
                 hcat = torch.mm(g2, w.permute(2, 0, 1).reshape(cout, k1 * cin)).view(n, 2, k1, cin)
                 dx, _ = _clenshaw(lap, [hcat[:, :, k, :] for k in range(k1)])
         return dx, dw, db, None, None
+
+
+class _ChebTermsFn(torch.autograd.Function):
+    """x [N, 2, F] -> stack_k T_k(L) x as [N, 2, K+1, F] (K SpMMs).  Backward: dx = sum_k T_k dZ_k by
+    Clenshaw (T_k Hermitian).  Building block of the multi-GPU layers, where the weight GEMM is applied
+    after a regrouping of the orders."""
+
+    @staticmethod
+    def forward(ctx, x, lap, n_terms):
+        ctx.lap, ctx.n_terms = lap, n_terms
+        return torch.stack(_cheb_terms(lap, x.contiguous(), n_terms), dim=2)
+
+    @staticmethod
+    def backward(ctx, dz):
+        dz = dz.contiguous()
+        ys = [dz[:, :, k, :].contiguous() for k in range(ctx.n_terms)]
+        dx, _ = _clenshaw(ctx.lap, ys)
+        return dx, None, None
+
+
+class _ClenshawFn(torch.autograd.Function):
+    """ycat [N, 2, K+1, F] -> sum_k T_k(L) ycat[:, :, k] + bias (+ complex ReLU) (K SpMMs, epilogue
+    fused).  Backward: dY_k = T_k G by the forward recursion."""
+
+    @staticmethod
+    def forward(ctx, ycat, bias, lap, relu):
+        k1 = ycat.size(2)
+        ys = [ycat[:, :, k, :].contiguous() for k in range(k1)]
+        out, mask = _clenshaw(lap, ys, None if bias is None else bias.detach(), relu)
+        ctx.lap, ctx.relu, ctx.mask, ctx.k1, ctx.has_bias = lap, relu, mask, k1, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.relu:
+            g = _relu_bwd_(g.clone(), ctx.mask)
+        db = g.sum(dim=(0, 1)) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        dy = torch.stack(_cheb_terms(ctx.lap, g, ctx.k1), dim=2) if ctx.needs_input_grad[0] else None
+        return dy, db, None, None
 
 
 class _ListConvFn(torch.autograd.Function):

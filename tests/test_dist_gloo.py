@@ -24,11 +24,23 @@ class ScipyOperator:
         self.m = sp.csr_matrix((v[:, 0] + 1j * v[:, 1], ci.numpy(), rp.numpy()), shape=(rp.numel() - 1, n_cols))
         self.nnz = int(ci.numel())
 
-    def spmm(self, X, out, alpha=1.0, z1=None, beta1=0.0):
-        x = X[:, 0, :].double().numpy() + 1j * X[:, 1, :].double().numpy()
-        y = alpha * (self.m @ x)
+    def spmm(self, X, out=None, alpha=1.0, z1=None, beta1=0.0, z2=None, beta2=0.0, bias=None, relu=False, mask=None):
+        c = lambda t: t[:, 0, :].detach().double().numpy() + 1j * t[:, 1, :].detach().double().numpy()
+        y = alpha * (self.m @ c(X))
         if z1 is not None:
-            y = y + beta1 * (z1[:, 0, :].double().numpy() + 1j * z1[:, 1, :].double().numpy())
+            y = y + beta1 * c(z1)
+        if z2 is not None:
+            y = y + beta2 * c(z2)
+        if bias is not None:
+            b = bias.detach().double().numpy().reshape(-1)
+            y = y + b + 1j * b
+        if relu:
+            m = y.real >= 0
+            y = y * m
+            if mask is not None:
+                mask.copy_(torch.from_numpy(m.astype(np.uint8)))
+        if out is None:
+            out = torch.empty((self.m.shape[0], 2, X.size(2)), dtype=torch.float32)
         out[:, 0, :] = torch.from_numpy(y.real).float()
         out[:, 1, :] = torch.from_numpy(y.imag).float()
         return out
@@ -103,6 +115,81 @@ def test_column_bounds():
     assert b[0] == 0 and b[-1] == 100 and all(x <= y for x, y in zip(b, b[1:])) and all(x % 4 == 0 for x in b[:-1])
     b = D.column_bounds(5, 4)
     assert b[0] == 0 and b[-1] == 5 and all(x <= y for x, y in zip(b, b[1:]))
+
+
+def _worker_train(rank, world, port, out_dir, layer):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import magnet_amd.layer.sparse_magnet as M
+        from magnet_amd.utils.hermitian import ChebBasis
+        # CPU rehearsal: the ReLU helpers normally call the HIP library; route them to torch here
+        def bias_relu_(p, bias, relu):
+            if bias is not None:
+                p += bias.detach().reshape(1, 1, -1)
+            if not relu:
+                return None
+            m = (p[:, 0, :] >= 0)
+            p *= m.unsqueeze(1).float()
+            return m.to(torch.uint8)
+        M._bias_relu_ = bias_relu_
+        M._relu_bwd_ = lambda g, mask: g.mul_(mask.unsqueeze(1).float())
+        L, rp, ci, val = _graph()
+        n, cin, Fh, K, ncls = L.shape[0], 6, 8, 2, 4
+        op = ScipyOperator(rp, ci, val, n)
+        torch.manual_seed(0)
+        net = M.ChebNet(cin, ChebBasis(op, K), None, num_filter=Fh, K=K, label_dim=ncls, activation=True, layer=layer)
+        g = torch.Generator().manual_seed(1)
+        X = torch.randn(n, cin, generator=g); y = torch.randint(0, ncls, (1, n), generator=g)
+        train = torch.rand(n, generator=g) < 0.5
+        sh = D.ShardedChebNet(net, op, n, rank, world)
+        r0, r1 = sh.r0, sh.r1
+        xp = torch.stack([X[r0:r1], X[r0:r1]], dim=1)
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
+        tr_rows = train[r0:r1].nonzero().squeeze(1); va_rows = (~train[r0:r1]).nonzero().squeeze(1)
+        losses = []
+        for _ in range(2):
+            tl, vl = sh.epoch(opt, xp, y[:, r0:r1], tr_rows, va_rows, int(train.sum()), int((~train).sum()))
+            losses.append((tl.item(), vl.item()))
+        torch.save({'losses': losses, 'state': {k: v.clone() for k, v in net.state_dict().items()}},
+                   os.path.join(out_dir, 't%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,layer', [(2, 2), (3, 3)])
+def test_sharded_chebnet_training_matches_single_process(world, layer, tmp_path):
+    mp.spawn(_worker_train, args=(world, _free_port(), str(tmp_path), layer), nprocs=world, join=True)
+    # single-process reference: the oracle's forward under autograd with the same initial weights
+    import magnet_amd.layer.sparse_magnet as M
+    from magnet_amd.utils.hermitian import ChebBasis
+    L, rp, ci, val = _graph()
+    n, cin, Fh, K, ncls = L.shape[0], 6, 8, 2, 4
+    torch.manual_seed(0)
+    net = M.ChebNet(cin, ChebBasis(ScipyOperator(rp, ci, val, n), K), None, num_filter=Fh, K=K, label_dim=ncls,
+                    activation=True, layer=layer)
+    state = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(n, cin, generator=g); y = torch.randint(0, ncls, (1, n), generator=g)
+    train = torch.rand(n, generator=g) < 0.5
+    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(L, K))
+    opt = torch.optim.Adam([state[k] for k, _ in net.named_parameters()], lr=5e-3, weight_decay=5e-4)
+    ref_losses = []
+    for _ in range(2):
+        preds = O.chebnet_forward(state, Lr, Li, X, X, layer, True)
+        loss = torch.nn.NLLLoss()(preds[:, :, train], y[:, train])
+        opt.zero_grad(); loss.backward(); opt.step()
+        with torch.no_grad():
+            v = torch.nn.NLLLoss()(O.chebnet_forward(state, Lr, Li, X, X, layer, True)[:, :, ~train], y[:, ~train])
+        ref_losses.append((loss.item(), v.item()))
+    outs = [torch.load(os.path.join(str(tmp_path), 't%d.pt' % r)) for r in range(world)]
+    for o in outs:
+        for (a, b), (c, d) in zip(o['losses'], ref_losses):
+            assert abs(a - c) <= 5e-5 * abs(c) and abs(b - d) <= 5e-5 * abs(d)
+        for k in state:
+            assert float((o['state'][k] - state[k].detach()).abs().max()) <= 5e-5 * float(state[k].detach().abs().max()) + 1e-6, k
 
 
 def _free_port():

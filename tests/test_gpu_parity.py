@@ -668,3 +668,27 @@ def test_spmm_full_size_properties():
         worst = max(worst, float((Y[r, 0, :].double() - re).abs().max()) / scale,
                     float((Y[r, 1, :].double() - im).abs().max()) / scale)
     assert worst <= 1e-5, worst
+
+
+def test_sharded_chebnet_single_rank_matches_chebnet_on_gpu():
+    """The multi-GPU network form (alternating GEMM-first / SpMM-first layers built from the
+    _ClenshawFn / _ChebTermsFn blocks) with one rank: same outputs and gradients as ChebNet."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd import dist as D
+    n, e, cin, Fh, K = 30000, 500000, 12, 16, 2
+    src, dst = lap.powerlaw_edges(n, e, 5, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.1)
+    for layer in (2, 3):
+        torch.manual_seed(1)
+        net = M.ChebNet(cin, H.cheb_poly_sparse(L, K), None, num_filter=Fh, K=K, label_dim=5, activation=True, layer=layer).to(DEV)
+        X = torch.randn(n, cin, device=DEV); y = torch.randint(0, 5, (1, n), device=DEV)
+        ref = net(X, X)
+        loss = torch.nn.NLLLoss()(ref, y); loss.backward()
+        gref = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net.zero_grad()
+        sh = D.ShardedChebNet(net, L, n, 0, 1)
+        out = sh.forward(torch.stack([X, X], dim=1))
+        assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), what='sharded forward')
+        torch.nn.NLLLoss()(out, y).backward()
+        for k, p in net.named_parameters():
+            assert_close(p.grad.cpu().numpy(), gref[k].cpu().numpy(), rel=2e-5, what='grad ' + k)
