@@ -71,6 +71,20 @@ def _rows2(p):
     return p.reshape(p.size(0) * 2, p.size(2))
 
 
+def _gram(a, b):
+    """a^T b for two tall matrices [R, m], [R, n] (R = 2N rows, m, n = channel counts): the weight
+    gradient.  A single GEMM has only m*n/tile^2 output tiles to spread over 256 CUs, so the rows are
+    cut into slabs that are multiplied as one batched GEMM and summed (split-K)."""
+    r = a.size(0)
+    if r >= (1 << 16) and a.size(1) * b.size(1) <= (1 << 18):
+        slabs = 1
+        while slabs < 128 and r % (slabs * 2) == 0 and r // (slabs * 2) >= 4096:
+            slabs *= 2
+        if slabs > 1:
+            return torch.bmm(a.view(slabs, r // slabs, -1).transpose(1, 2), b.view(slabs, r // slabs, -1)).sum(0)
+    return torch.mm(a.t(), b)
+
+
 def _bias_relu_(p, bias, relu):
     """In place: + bias on both parts, complex ReLU; returns the uint8 mask (or None)."""
     n, _, f = p.shape
@@ -176,7 +190,7 @@ class _ChebConvFn(torch.autograd.Function):
         if ctx.gemm_first:
             ds = _cheb_terms(lap, g, k1) if (need_w or need_x) else None     # T_k G
             if need_w:
-                dw = torch.stack([torch.mm(_rows2(xp).t(), _rows2(d)) for d in ds])
+                dw = torch.stack([_gram(_rows2(xp), _rows2(d)) for d in ds])
             if need_x:
                 dx2 = torch.mm(_rows2(ds[0]), w[0].t())
                 for k in range(1, k1):
@@ -184,7 +198,7 @@ class _ChebConvFn(torch.autograd.Function):
                 dx = dx2.view(n, 2, cin)
         else:
             if need_w:
-                dw = torch.stack([torch.mm(_rows2(z).t(), g2) for z in ctx.zs])
+                dw = torch.stack([_gram(_rows2(z), g2) for z in ctx.zs])
             if need_x:
                 hcat = torch.mm(g2, w.permute(2, 0, 1).reshape(cout, k1 * cin)).view(n, 2, k1, cin)
                 dx, _ = _clenshaw(lap, [hcat[:, :, k, :] for k in range(k1)])
@@ -267,7 +281,7 @@ class _ListConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
             for k, z in enumerate(ctx.zs):
-                dw[k] = torch.mm(_rows2(z).t(), g2)
+                dw[k] = _gram(_rows2(z), g2)
         if ctx.needs_input_grad[0]:
             for k, lap in enumerate(ctx.laps):
                 h = torch.mm(g2, w[k].t()).view(g.size(0), 2, cin)
