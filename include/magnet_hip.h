@@ -122,6 +122,27 @@ int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, const float
                      const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
                      float* scratch, size_t scratch_bytes, void* stream);
 
+/* Whole recursions in one call (the loop over orders of ChebConv.forward,
+ * src/layer/sparse_magnet.py:60-68, with the polynomials of src/utils/hermitian.py:117-134
+ * applied to features instead of being formed).  Matrices are contiguous row-planar
+ * [n][2][F]; `order_stride` is the distance in floats between consecutive orders.
+ *   mh_cheb_terms: Z[0] = X is given; fills Z[k] = T_k(L) X for k = 1 .. n_terms-1
+ *                  (Z_1 = L Z_0, Z_k = 2 L Z_{k-1} - Z_{k-2}); n_terms-1 SpMM launches.
+ *   mh_clenshaw  : out = sum_k T_k(L) Y_k [+ bias][complex ReLU] by Clenshaw's recurrence
+ *                  b_k = Y_k + 2 L b_{k+1} - b_{k+2}; n_terms-1 SpMM launches, the epilogue fused
+ *                  into the last; `work` = two matrices of scratch (needed when n_terms > 2).
+ * plan / scratch as for mh_cspmm_planned (NULL / 0: no hub-row plan).
+ */
+int mh_cheb_terms(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n,
+                  float* Z, int64_t order_stride, int32_t n_terms, int32_t F,
+                  const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
+                  float* scratch, size_t scratch_bytes, void* stream);
+int mh_clenshaw(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n,
+                const float* Y, int64_t order_stride, int32_t n_terms, float* work, float* out,
+                const float* bias, int relu, uint8_t* mask_out, int32_t F,
+                const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
+                float* scratch, size_t scratch_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Layout and activation helpers around the SpMM.
  */
@@ -132,6 +153,18 @@ int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, const float
  * src/layer/sparse_magnet.py:121 is the same memory as the packed result. */
 int mh_pack(const float* re, int64_t ld_re, const float* im_, int64_t ld_im,
             float* out, int64_t ld, int64_t im, int64_t n_rows, int32_t F, void* stream);
+
+/* Inverse of mh_pack: row-planar in -> (real[N][F], imag[N][F]). */
+int mh_unpack(const float* in, int64_t ld, int64_t im, float* re, int64_t ld_re, float* im_, int64_t ld_im,
+              int64_t n_rows, int32_t F, void* stream);
+
+/* Halo staging for a row-partitioned run: rows idx[0..n_idx) of a row-planar matrix to / from
+ * a dense buffer [n_idx][2][F] (the send / receive buffer of a boundary-row exchange).  No
+ * counterpart in the single-device reference. */
+int mh_gather_rows(const float* X, int64_t ld, int64_t im, const int32_t* idx, int64_t n_idx,
+                   float* buf, int32_t F, void* stream);
+int mh_scatter_rows(const float* buf, const int32_t* idx, int64_t n_idx,
+                    float* X, int64_t ld, int64_t im, int32_t F, void* stream);
 
 /* In place on row-planar Y: add bias[F] to both parts (NULL = none), then the
  * complex ReLU when relu != 0, storing the mask when mask_out != NULL.

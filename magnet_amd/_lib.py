@@ -48,6 +48,16 @@ def _load():
     lib.mh_cspmm_plan_count.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32), vp]
     lib.mh_cspmm_plan_fill.restype = C.c_int
     lib.mh_cspmm_plan_fill.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.mh_cheb_terms.restype = C.c_int
+    lib.mh_cheb_terms.argtypes = [vp, vp, vp, i32, vp, i64, i32, i32, vp, i32, i32, i32, vp, sz, vp]
+    lib.mh_clenshaw.restype = C.c_int
+    lib.mh_clenshaw.argtypes = [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, C.c_int, vp, i32, vp, i32, i32, i32, vp, sz, vp]
+    lib.mh_unpack.restype = C.c_int
+    lib.mh_unpack.argtypes = [vp, i64, i64, vp, i64, vp, i64, i64, i32, vp]
+    lib.mh_gather_rows.restype = C.c_int
+    lib.mh_gather_rows.argtypes = [vp, i64, i64, vp, i64, vp, i32, vp]
+    lib.mh_scatter_rows.restype = C.c_int
+    lib.mh_scatter_rows.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
     lib.mh_pack.restype = C.c_int
     lib.mh_pack.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i32, vp]
     lib.mh_bias_relu.restype = C.c_int
@@ -62,7 +72,8 @@ def _load():
 lib = _load()
 
 EXPORTS = ['mh_version', 'mh_last_error', 'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
-           'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
+           'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill', 'mh_cheb_terms', 'mh_clenshaw', 'mh_unpack', 'mh_gather_rows',
+           'mh_scatter_rows', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
 
 
 def check(rc):

@@ -97,6 +97,36 @@ __global__ void __launch_bounds__(kBlock) bias_relu_kernel(float* __restrict__ Y
     }
 }
 
+// row-planar -> two planar matrices
+__global__ void __launch_bounds__(kBlock) unpack_kernel(const float* __restrict__ in, int64_t ld, int64_t im,
+                                                        float* __restrict__ re, int64_t ld_re, float* __restrict__ im_,
+                                                        int64_t ld_im, int64_t n_rows, int32_t F) {
+    const int64_t total = n_rows * 2 * F;
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < total; t += int64_t(gridDim.x) * kBlock) {
+        int64_t r = t / (2 * F);
+        int rem = int(t - r * 2 * F);
+        int part = rem / F, c = rem - part * F;
+        float v = in[r * ld + (part ? im : 0) + c];
+        if (part) im_[r * ld_im + c] = v; else re[r * ld_re + c] = v;
+    }
+}
+
+// rows idx[i] of a row-planar matrix <-> row i of a dense buffer [n_idx][2][F]; one wave per row
+template <bool GATHER>
+__global__ void __launch_bounds__(kBlock) move_rows_kernel(float* __restrict__ X, int64_t ld, int64_t im,
+                                                           const int32_t* __restrict__ idx, int64_t n_idx,
+                                                           float* __restrict__ buf, int32_t F) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6; i < n_idx; i += (int64_t(gridDim.x) * kBlock) >> 6) {
+        float* xr = X + int64_t(idx[i]) * ld;
+        float* b = buf + i * 2 * F;
+        for (int c = lane; c < F; c += 64) {
+            if (GATHER) { b[c] = xr[c]; b[F + c] = xr[im + c]; }
+            else { xr[c] = b[c]; xr[im + c] = b[F + c]; }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) relu_bwd_kernel(float* __restrict__ G, int64_t ld, int64_t im,
                                                           const uint8_t* __restrict__ mask, int64_t n_rows, int32_t F) {
     const int64_t total = n_rows * F;
@@ -195,5 +225,41 @@ extern "C" int mh_powerlaw_edges(int32_t n_nodes, int64_t n_edges, uint64_t seed
     MH_REQUIRE(src && dst, "null pointer");
     powerlaw_kernel<<<grid_for(n_edges, 1 << 16), kBlock, 0, stream>>>(n_nodes, n_edges, seed, first_edge, src, dst);
     MH_LAUNCH_CHECK("powerlaw_edges");
+    return MH_OK;
+}
+
+extern "C" int mh_unpack(const float* in, int64_t ld, int64_t im, float* re, int64_t ld_re, float* im_, int64_t ld_im,
+                         int64_t n_rows, int32_t F, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MH_REQUIRE(n_rows >= 0 && F >= 1, "n_rows=%lld F=%d", (long long)n_rows, F);
+    if (n_rows == 0) return MH_OK;
+    MH_REQUIRE(in && re && im_, "null pointer");
+    MH_REQUIRE(ld_re >= F && ld_im >= F && ld >= F && im >= F, "stride smaller than F");
+    unpack_kernel<<<grid_for(n_rows * 2 * F, 1 << 20), kBlock, 0, stream>>>(in, ld, im, re, ld_re, im_, ld_im, n_rows, F);
+    MH_LAUNCH_CHECK("unpack");
+    return MH_OK;
+}
+
+extern "C" int mh_gather_rows(const float* X, int64_t ld, int64_t im, const int32_t* idx, int64_t n_idx, float* buf,
+                              int32_t F, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MH_REQUIRE(n_idx >= 0 && F >= 1, "n_idx=%lld F=%d", (long long)n_idx, F);
+    if (n_idx == 0) return MH_OK;
+    MH_REQUIRE(X && idx && buf, "null pointer");
+    MH_REQUIRE(ld >= F && im >= F, "stride smaller than F");
+    move_rows_kernel<true><<<grid_for(n_idx * 64, 1 << 16), kBlock, 0, stream>>>(const_cast<float*>(X), ld, im, idx, n_idx, buf, F);
+    MH_LAUNCH_CHECK("gather_rows");
+    return MH_OK;
+}
+
+extern "C" int mh_scatter_rows(const float* buf, const int32_t* idx, int64_t n_idx, float* X, int64_t ld, int64_t im,
+                               int32_t F, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MH_REQUIRE(n_idx >= 0 && F >= 1, "n_idx=%lld F=%d", (long long)n_idx, F);
+    if (n_idx == 0) return MH_OK;
+    MH_REQUIRE(X && idx && buf, "null pointer");
+    MH_REQUIRE(ld >= F && im >= F, "stride smaller than F");
+    move_rows_kernel<false><<<grid_for(n_idx * 64, 1 << 16), kBlock, 0, stream>>>(X, ld, im, idx, n_idx, const_cast<float*>(buf), F);
+    MH_LAUNCH_CHECK("scatter_rows");
     return MH_OK;
 }

@@ -524,3 +524,64 @@ extern "C" int mh_cspmm_plan_fill(const int32_t* row_ptr, int32_t n_rows, int32_
     MH_LAUNCH_CHECK("plan_fill");
     return MH_OK;
 }
+
+// ---- whole recursions in one call (K SpMM launches on the stream) ---------------------------
+namespace {
+struct PlanArgs { const int32_t* plan; int32_t n_long, n_chunks, chunk; float* scratch; size_t scratch_bytes; };
+int spmm_sq(const int32_t* rp, const int32_t* ci, const float* val, int32_t n, const float* X, float* Y, float alpha,
+            const float* Z1, float b1, const float* Z2, float b2, const float* bias, int relu, uint8_t* mask, int32_t F,
+            const PlanArgs& p, void* stream) {
+    const int64_t ld = 2 * int64_t(F), im = F;
+    return mh_cspmm_planned(rp, ci, val, n, X, ld, im, Y, ld, im, alpha, Z1, ld, im, b1, Z2, ld, im, b2, bias, relu, mask, F,
+                            p.plan, p.n_long, p.n_chunks, p.chunk, p.scratch, p.scratch_bytes, stream);
+}
+}  // namespace
+
+extern "C" int mh_cheb_terms(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n,
+                             float* Z, int64_t order_stride, int32_t n_terms, int32_t F, const int32_t* plan,
+                             int32_t n_long, int32_t n_chunks, int32_t chunk, float* scratch, size_t scratch_bytes,
+                             void* stream) {
+    MH_REQUIRE(n >= 0 && n_terms >= 1 && F >= 1, "n=%d n_terms=%d F=%d", n, n_terms, F);
+    if (n == 0 || n_terms == 1) return MH_OK;
+    MH_REQUIRE(Z != nullptr, "Z is null");
+    MH_REQUIRE(order_stride >= int64_t(n) * 2 * F, "order_stride smaller than one matrix");
+    PlanArgs p{plan, n_long, n_chunks, chunk, scratch, scratch_bytes};
+    for (int k = 1; k < n_terms; ++k) {
+        float* zk = Z + int64_t(k) * order_stride;
+        const float* zp = Z + int64_t(k - 1) * order_stride;
+        int rc = (k == 1) ? spmm_sq(row_ptr, col_idx, val, n, zp, zk, 1.0f, nullptr, 0.f, nullptr, 0.f, nullptr, 0, nullptr, F, p, stream)
+                          : spmm_sq(row_ptr, col_idx, val, n, zp, zk, 2.0f, Z + int64_t(k - 2) * order_stride, -1.0f,
+                                    nullptr, 0.f, nullptr, 0, nullptr, F, p, stream);
+        if (rc != MH_OK) return rc;
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_clenshaw(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n, const float* Y,
+                           int64_t order_stride, int32_t n_terms, float* work, float* out, const float* bias, int relu,
+                           uint8_t* mask_out, int32_t F, const int32_t* plan, int32_t n_long, int32_t n_chunks,
+                           int32_t chunk, float* scratch, size_t scratch_bytes, void* stream) {
+    MH_REQUIRE(n >= 0 && n_terms >= 1 && F >= 1, "n=%d n_terms=%d F=%d", n, n_terms, F);
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(Y && out, "Y/out is null");
+    MH_REQUIRE(order_stride >= int64_t(n) * 2 * F, "order_stride smaller than one matrix");
+    const int64_t mat = int64_t(n) * 2 * F;
+    PlanArgs p{plan, n_long, n_chunks, chunk, scratch, scratch_bytes};
+    if (n_terms == 1) {
+        MH_HIP(hipMemcpyAsync(out, Y, size_t(mat) * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+        return mh_bias_relu(out, 2 * int64_t(F), F, bias, relu, mask_out, n, F, stream);
+    }
+    MH_REQUIRE(n_terms == 2 || work != nullptr, "work (two matrices) is needed for n_terms > 2");
+    // b_K = Y_K ; b_k = Y_k + 2 L b_{k+1} - b_{k+2} ; result = Y_0 + L b_1 - b_2
+    const float* b1 = Y + int64_t(n_terms - 1) * order_stride;
+    const float* b2 = nullptr;
+    int slot = 0;
+    for (int k = n_terms - 2; k >= 1; --k) {
+        float* nb = work + int64_t(slot) * mat;
+        int rc = spmm_sq(row_ptr, col_idx, val, n, b1, nb, 2.0f, Y + int64_t(k) * order_stride, 1.0f, b2, -1.0f, nullptr, 0,
+                         nullptr, F, p, stream);
+        if (rc != MH_OK) return rc;
+        b2 = b1; b1 = nb; slot ^= 1;
+    }
+    return spmm_sq(row_ptr, col_idx, val, n, b1, out, 1.0f, Y, 1.0f, b2, -1.0f, bias, relu, mask_out, F, p, stream);
+}

@@ -49,6 +49,41 @@ def pack_complex(real, imag, out=None):
     return out
 
 
+def unpack_complex(p):
+    """Row-planar [N, 2, F] -> two contiguous planar matrices (mh_unpack); p[:, 0], p[:, 1] are free views
+    when strided results are acceptable."""
+    require_cuda(p)
+    ld, im = _packed_strides(p, 'p')
+    n, _, f = p.shape
+    re = torch.empty((n, f), dtype=torch.float32, device=p.device); imag = torch.empty_like(re)
+    if n:
+        check(_lib.lib.mh_unpack(ptr(p), ld, im, ptr(re), f, ptr(imag), f, n, f, stream_ptr(p.device)))
+    return re, imag
+
+
+def gather_rows(x, idx, out=None):
+    """Rows idx of row-planar x into a dense [len(idx), 2, F] buffer (mh_gather_rows): halo send staging."""
+    require_cuda(x, idx)
+    ld, im = _packed_strides(x, 'x')
+    idx = idx.to(torch.int32).contiguous()
+    f = x.size(2)
+    if out is None:
+        out = torch.empty((idx.numel(), 2, f), dtype=torch.float32, device=x.device)
+    check(_lib.lib.mh_gather_rows(ptr(x), ld, im, ptr(idx), idx.numel(), ptr(out), f, stream_ptr(x.device)))
+    return out
+
+
+def scatter_rows(buf, idx, x):
+    """Row i of dense buf [len(idx), 2, F] into row idx[i] of row-planar x (mh_scatter_rows): halo receive."""
+    require_cuda(x, idx, buf)
+    ld, im = _packed_strides(x, 'x')
+    idx = idx.to(torch.int32).contiguous()
+    if not buf.is_contiguous() or buf.size(0) != idx.numel() or buf.size(2) != x.size(2):
+        raise MagnetHipError('buf must be contiguous [len(idx), 2, F]')
+    check(_lib.lib.mh_scatter_rows(ptr(buf), ptr(idx), idx.numel(), ptr(x), ld, im, x.size(2), stream_ptr(x.device)))
+    return x
+
+
 class MagneticLaplacian:
     """Complex CSR on the device: row_ptr int32 [n_rows+1], col_idx int32 [nnz],
     val float32 [nnz, 2] (re, im).  `n_cols` rows of the operand are addressed by col_idx."""
@@ -145,6 +180,44 @@ class MagneticLaplacian:
             ev1.record(torch.cuda.current_stream(X.device))
             obs(ev0, ev1, dict(nnz=self.nnz, n_rows=self.n_rows, F=f, n_addends=int(z1 is not None) + int(z2 is not None)))
         return out
+
+    def _plan_args(self, f, device):
+        plan, n_long, n_chunks, chunk = self.plan()
+        scratch = torch.empty(n_chunks * 2 * f, dtype=torch.float32, device=device) if n_long > 0 else None
+        return [ptr(plan), n_long, n_chunks, chunk, ptr(scratch), 0 if scratch is None else scratch.numel() * 4]
+
+    def cheb_terms(self, x0, n_terms):
+        """[T_0 x0, ..., T_{n_terms-1} x0] as one tensor [n_terms, N, 2, F] (mh_cheb_terms: the whole
+        recursion in one library call)."""
+        require_cuda(x0)
+        _packed_strides(x0, 'x0')
+        if self.n_rows != self.n_cols or x0.size(0) != self.n_cols:
+            raise MagnetHipError('cheb_terms needs a square Laplacian and %d feature rows' % self.n_cols)
+        n, _, f = x0.shape
+        z = torch.empty((n_terms, n, 2, f), dtype=torch.float32, device=x0.device)
+        z[0].copy_(x0)
+        check(_lib.lib.mh_cheb_terms(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), n, ptr(z), n * 2 * f, n_terms, f,
+                                     *self._plan_args(f, x0.device), stream_ptr(x0.device)))
+        return z
+
+    def clenshaw(self, y, bias=None, relu=False):
+        """sum_k T_k y[k] (+ bias, complex ReLU) for y [n_terms, N, 2, F] contiguous (mh_clenshaw).
+        Returns (out [N, 2, F], mask or None)."""
+        require_cuda(y, bias)
+        if y.dim() != 4 or y.size(2) != 2 or not y.is_contiguous() or y.dtype != torch.float32:
+            raise MagnetHipError('y must be contiguous float32 [n_terms, N, 2, F]')
+        k1, n, _, f = y.shape
+        if self.n_rows != self.n_cols or n != self.n_cols:
+            raise MagnetHipError('clenshaw needs a square Laplacian and %d feature rows' % self.n_cols)
+        out = torch.empty((n, 2, f), dtype=torch.float32, device=y.device)
+        work = torch.empty((2, n, 2, f), dtype=torch.float32, device=y.device) if k1 > 2 else None
+        mask = torch.empty((n, f), dtype=torch.uint8, device=y.device) if relu else None
+        if bias is not None:
+            bias = bias.reshape(-1).float().contiguous()
+        check(_lib.lib.mh_clenshaw(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), n, ptr(y), n * 2 * f, k1, ptr(work),
+                                   ptr(out), ptr(bias), int(bool(relu)), ptr(mask), f, *self._plan_args(f, y.device),
+                                   stream_ptr(y.device)))
+        return out, mask
 
     # -- conversions ----------------------------------------------------------
     def to_scipy(self):

@@ -692,3 +692,47 @@ def test_sharded_chebnet_single_rank_matches_chebnet_on_gpu():
         torch.nn.NLLLoss()(out, y).backward()
         for k, p in net.named_parameters():
             assert_close(p.grad.cpu().numpy(), gref[k].cpu().numpy(), rel=2e-5, what='grad ' + k)
+
+
+def test_recursion_entry_points_and_row_staging(small_graph):
+    """mh_cheb_terms / mh_clenshaw (whole recursions in one library call), mh_unpack, mh_gather_rows /
+    mh_scatter_rows against fp64 scipy."""
+    _, lap, _, _, _ = _mods()
+    L, Ls = small_graph
+    n = L.n_rows
+    for f in (16, 6, 256):
+        x = _rand_packed(n, f, 3)
+        z = L.cheb_terms(x, 4)
+        ref = [_to_c(x), Ls @ _to_c(x)]
+        for k in (2, 3):
+            ref.append(2 * (Ls @ ref[k - 1]) - ref[k - 2])
+        for k in range(4):
+            got = _to_c(z[k])
+            assert_close(got.real, ref[k].real, what='T%d re' % k); assert_close(got.imag, ref[k].imag, what='T%d im' % k)
+        for k1 in (1, 2, 4):
+            y = torch.randn(k1, n, 2, f, generator=torch.Generator().manual_seed(k1)).to(DEV)
+            b = torch.randn(f, generator=torch.Generator().manual_seed(9)).to(DEV)
+            out, mask = L.clenshaw(y, bias=b)
+            want = 0
+            for k in range(k1):
+                t = [_to_c(y[k]), Ls @ _to_c(y[k])]
+                for j in range(2, k + 1):
+                    t.append(2 * (Ls @ t[j - 1]) - t[j - 2])
+                want = want + t[k]
+            bb = b.cpu().double().numpy()
+            want = want + bb + 1j * bb
+            got = _to_c(out)
+            assert_close(got.real, want.real, what='clenshaw re'); assert_close(got.imag, want.imag, what='clenshaw im')
+            out_r, mask = L.clenshaw(y, bias=b, relu=True)
+            safe = np.abs(want.real) > 1e-4 * np.abs(want).max()
+            m = want.real >= 0
+            assert np.array_equal(mask.cpu().numpy().astype(bool)[safe], m[safe])
+            assert_close(np.where(safe, _to_c(out_r), want * m).real, (want * m).real)
+        re, im = lap.unpack_complex(x)
+        assert torch.equal(re, x[:, 0, :]) and torch.equal(im, x[:, 1, :])
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:777].to(DEV)
+        buf = lap.gather_rows(x, idx)
+        assert torch.equal(buf, x[idx.long()])
+        tgt = torch.zeros_like(x)
+        lap.scatter_rows(buf, idx, tgt)
+        assert torch.equal(tgt[idx.long()], x[idx.long()]) and int((tgt.abs().sum((1, 2)) > 0).sum()) == 777
