@@ -18,11 +18,13 @@ Row partition
   balanced by work (nonzeros + rows).  Rank p computes rows [b_p, b_{p+1}) of each order.
 * Every rank keeps FULL-height feature buffers [N, 2, F] indexed by global node id (288 GB of
   HBM make that affordable: 20 GB per order at N = 10M, F = 256), so the CSR keeps its global
-  column ids and the exchange needs no packing: after computing its block of Z_k a rank sends that
-  block to every peer and receives the peers' blocks straight into place.  The transfers are
-  point-to-point sends/receives issued as one batch: on the fully connected xGMI mesh every pair
-  of GPUs has its own link, so all 7 peers are served concurrently (a ring would push 7x the
-  bytes through one link).
+  column ids.  After computing its block of Z_k a rank sends every peer the rows that peer's block
+  references (its boundary rows for that peer) and receives the rows it references itself.  On a
+  graph without locality that is the whole block, which then travels in place with no packing; on
+  a graph with locality only the boundary rows travel, packed by a row-gather kernel and scattered
+  into place on arrival.  The transfers are point-to-point sends/receives issued as one batch: on
+  the fully connected xGMI mesh every pair of GPUs has its own link, so all 7 peers are served
+  concurrently (a ring would push 7x the bytes through one link).
 * To overlap the exchange with compute the local block of the Laplacian is split by COLUMN into
   L_int (columns inside the rank's own row block: operands already local) and L_ext (all other
   columns).  Order k runs  Z_k[blk] = a L_int Z_{k-1} + b Z_{k-2}[blk]  while the exchange of
@@ -97,42 +99,130 @@ def wait_all(works):
         w.wait()
 
 
+class TorchRowMover:
+    """Index-based stand-in for the halo staging kernels (CPU rehearsal over gloo)."""
+
+    @staticmethod
+    def gather(x, idx):
+        return x[idx.long()].contiguous()
+
+    @staticmethod
+    def scatter(buf, idx, x):
+        x[idx.long()] = buf
+
+
+class HipRowMover:
+    """Halo staging on the GPU (mh_gather_rows / mh_scatter_rows)."""
+
+    @staticmethod
+    def gather(x, idx):
+        from .laplacian import gather_rows
+        return gather_rows(x, idx)
+
+    @staticmethod
+    def scatter(buf, idx, x):
+        from .laplacian import scatter_rows
+        scatter_rows(buf, idx, x)
+
+
 class RowPartition:
     """The rank's share of a Laplacian: its row block split into local-column and remote-column
-    parts, and the exchange of freshly computed row blocks.  `make_operator(rp, ci, val, n_cols)`
-    turns CSR tensors into an object with .spmm(X, out=, alpha=, z1=, beta1=) — the HIP
-    MagneticLaplacian in production."""
+    parts, and the exchange of freshly computed rows.  `make_operator(rp, ci, val, n_cols)` turns CSR
+    tensors into an object with .spmm(X, out=, alpha=, z1=, beta1=) — the HIP MagneticLaplacian in
+    production.
 
-    def __init__(self, row_ptr, col_idx, val, n, rank, world, make_operator, group=None):
+    Exchange: for every peer p the rank knows `give[p]` (its rows that some row of p's block
+    references: the boundary rows p needs) and `need[p]` (the rows of p's block its own L_ext
+    references).  When a peer needs most of the block (>= dense_fraction of its rows — always the case
+    on a graph without locality) the whole block is sent in place; otherwise only the boundary rows
+    travel: packed with the row-gather kernel, received into a staging buffer and scattered into
+    the full-height buffer before the remote-column SpMM runs."""
+
+    def __init__(self, row_ptr, col_idx, val, n, rank, world, make_operator, group=None, row_mover=None,
+                 dense_fraction=0.75):
         self.n, self.rank, self.world, self.group = n, rank, world, group
-        self.bounds = partition_bounds(row_ptr, world)
-        self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        self.mover = row_mover or (HipRowMover if row_ptr.is_cuda else TorchRowMover)
+        self.bounds = b = partition_bounds(row_ptr, world)
+        self.r0, self.r1 = b[rank], b[rank + 1]
         rp, ci, v = slice_rows(row_ptr, col_idx, val, self.r0, self.r1)
         self.local_nnz = int(ci.numel())
         (rpi, cii, vi), (rpe, cie, ve) = split_columns(rp, ci, v, self.r0, self.r1)
         self.L_int = make_operator(rpi, cii, vi, n)
         self.L_ext = make_operator(rpe, cie, ve, n)
+        # boundary sets; every rank derives them from the same CSR, so sender and receiver agree
+        dev = row_ptr.device
+        self.give, self.need = [None] * world, [None] * world
+        cols_ext = cie.long()
+        for p in range(world):
+            if p == rank:
+                continue
+            m = torch.zeros(b[p + 1] - b[p], dtype=torch.bool, device=dev)          # rows of p that I reference
+            sel = cols_ext[(cols_ext >= b[p]) & (cols_ext < b[p + 1])]
+            m[sel - b[p]] = True
+            need = m.nonzero().squeeze(1) + b[p]
+            self.need[p] = None if need.numel() >= dense_fraction * max(b[p + 1] - b[p], 1) else need.to(torch.int32)
+            a, z = int(row_ptr[b[p]]), int(row_ptr[b[p + 1]])                      # my rows that p references
+            cp = col_idx[a:z].long()
+            m = torch.zeros(self.r1 - self.r0, dtype=torch.bool, device=dev)
+            m[cp[(cp >= self.r0) & (cp < self.r1)] - self.r0] = True
+            give = m.nonzero().squeeze(1) + self.r0
+            self.give[p] = None if give.numel() >= dense_fraction * max(self.r1 - self.r0, 1) else give.to(torch.int32)
 
     def block(self, full):
         return full[self.r0:self.r1]
 
     def exchange(self, full):
-        return exchange_blocks(full, self.bounds, self.rank, self.world, self.group)
+        """Start sending my freshly computed rows and receiving the peers'.  Returns a handle for
+        finish_exchange()."""
+        if self.world == 1:
+            return None
+        b, ops, staged = self.bounds, [], []
+        f = full.size(2)
+        for step in range(1, self.world):
+            to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
+            if self.give[to] is None:
+                mine = full[self.r0:self.r1]
+            else:
+                mine = self.mover.gather(full, self.give[to])
+            if mine.numel():
+                ops.append(dist.P2POp(dist.isend, mine, to, self.group))
+                staged.append(mine)                                  # keep the send buffer alive
+            if self.need[frm] is None:
+                blk = full[b[frm]:b[frm + 1]]
+                if blk.numel():
+                    ops.append(dist.P2POp(dist.irecv, blk, frm, self.group))
+            elif self.need[frm].numel():
+                buf = torch.empty((self.need[frm].numel(), 2, f), dtype=full.dtype, device=full.device)
+                ops.append(dist.P2POp(dist.irecv, buf, frm, self.group))
+                staged.append((buf, self.need[frm]))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return (works, staged, full)
 
-    def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=()):
-        """z_out[blk] = alpha * (L z_prev)[blk] + beta * z_prev2[blk].  `pending` are the handles of
-        the exchange that completes z_prev; only the remote-column part waits for them."""
+    def finish_exchange(self, handle):
+        """Wait for an exchange and move staged boundary rows into place."""
+        if not handle:
+            return
+        works, staged, full = handle
+        wait_all(works)
+        for item in staged:
+            if isinstance(item, tuple):
+                self.mover.scatter(item[0], item[1], full)
+
+    def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=None):
+        """z_out[blk] = alpha * (L z_prev)[blk] + beta * z_prev2[blk].  `pending` is the handle of the
+        exchange that completes z_prev; only the remote-column part waits for it."""
         blk = self.block(z_out)
         self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta)
-        wait_all(pending)
+        self.finish_exchange(pending)
         self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
         return blk
 
     def cheb_terms(self, x_full, n_terms, buffers=None):
-        """Row blocks of [T_0 x, ..., T_{n-1} x]; x_full must be complete on every rank.
-        Returns (list of full-height buffers, handles of the last exchange or [])."""
+        """[T_0 x, ..., T_{n-1} x] as full-height buffers of which this rank's row block (and, for
+        all but the last order, every row this rank references) is valid; x_full must hold every row
+        this rank references."""
         zs = [x_full]
-        pending = []
+        pending = None
         for k in range(1, n_terms):
             z = buffers[k - 1] if buffers is not None else torch.empty_like(x_full)
             if k == 1:
@@ -140,7 +230,7 @@ class RowPartition:
             else:
                 self.propagate(zs[k - 1], z, 2.0, zs[k - 2], -1.0, pending=pending)
             zs.append(z)
-            pending = self.exchange(z) if k < n_terms - 1 else []
+            pending = self.exchange(z) if k < n_terms - 1 else None
         return zs
 
 

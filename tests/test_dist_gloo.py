@@ -53,20 +53,32 @@ def _graph(n=400, e=6000, seed=4):
     return L, torch.from_numpy(L.indptr), torch.from_numpy(L.indices), val
 
 
-def _worker(rank, world, port, n_terms, out_dir):
+def _banded_graph(n=600, reach=6, seed=2):
+    """A graph with locality: node i points to a few nodes within `reach` of it (ring), so a row block's
+    halo is a thin band of its neighbours' blocks."""
+    rng = np.random.default_rng(seed)
+    src = np.repeat(np.arange(n), 3)
+    dst = (src + rng.integers(1, reach + 1, len(src))) % n
+    L = O.hermitian_decomp_sparse(src, dst, n, 0.2)
+    val = torch.from_numpy(np.stack([L.data.real, L.data.imag], 1).astype(np.float32))
+    return L, torch.from_numpy(L.indptr), torch.from_numpy(L.indices), val
+
+
+def _worker(rank, world, port, n_terms, out_dir, banded=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        L, rp, ci, val = _graph()
+        L, rp, ci, val = _banded_graph() if banded else _graph()
         n = L.shape[0]
         part = D.RowPartition(rp, ci, val, n, rank, world, ScipyOperator)
         x = torch.randn(n, 2, 5, generator=torch.Generator().manual_seed(0))
         zs = part.cheb_terms(x, n_terms)
         blocks = [part.block(z).clone() for z in zs]
-        # after the last exchange every earlier order is complete on every rank
+        # after an order's exchange every row this rank references is valid (all rows when blocks travel whole)
         complete = [z.clone() for z in zs[:-1]]
         torch.save({'bounds': part.bounds, 'blocks': blocks, 'complete': complete,
+                    'dense': [g is None for g in part.give],
                     'nnz': (part.L_int.nnz, part.L_ext.nnz, part.local_nnz)}, os.path.join(out_dir, 'r%d.pt' % rank))
         dist.barrier()
     finally:
@@ -197,11 +209,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_row_partitioned_recursion_matches_single_process(world, tmp_path):
+@pytest.mark.parametrize('world,banded', [(2, False), (3, False), (3, True), (4, True)])
+def test_row_partitioned_recursion_matches_single_process(world, banded, tmp_path):
     n_terms = 4
-    mp.spawn(_worker, args=(world, _free_port(), n_terms, str(tmp_path)), nprocs=world, join=True)
-    L, rp, ci, val = _graph()
+    mp.spawn(_worker, args=(world, _free_port(), n_terms, str(tmp_path), banded), nprocs=world, join=True)
+    L, rp, ci, val = _banded_graph() if banded else _graph()
     n = L.shape[0]
     x = torch.randn(n, 2, 5, generator=torch.Generator().manual_seed(0))
     xc = x[:, 0, :].double().numpy() + 1j * x[:, 1, :].double().numpy()
@@ -219,9 +231,13 @@ def test_row_partitioned_recursion_matches_single_process(world, tmp_path):
             got = o['blocks'][k][:, 0, :].double().numpy() + 1j * o['blocks'][k][:, 1, :].double().numpy()
             want = ref[k][bounds[r]:bounds[r + 1]]
             assert np.abs(got - want).max() <= 1e-5 * np.abs(ref[k]).max()
-        for k in range(n_terms - 1):
-            got = o['complete'][k][:, 0, :].double().numpy() + 1j * o['complete'][k][:, 1, :].double().numpy()
-            assert np.abs(got - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max()
+        if banded:
+            assert not any(d for p, d in enumerate(o['dense']) if p != r)     # only boundary rows travelled
+        else:
+            assert all(o['dense'])                                            # power-law graph: whole blocks
+            for k in range(n_terms - 1):
+                got = o['complete'][k][:, 0, :].double().numpy() + 1j * o['complete'][k][:, 1, :].double().numpy()
+                assert np.abs(got - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max()
 
 
 def test_partition_bounds_balance_and_edge_cases():
