@@ -56,3 +56,17 @@ def test_product_path_refuses_cpu_tensors():
     from magnet_amd import MagnetHipError, pack_complex
     with pytest.raises(MagnetHipError):
         pack_complex(torch.zeros(3, 4), torch.zeros(3, 4))
+
+
+def test_int32_range_is_checked_before_any_memory_is_touched():
+    from magnet_amd import _lib
+    lib = _lib.lib
+    fake = C.c_void_p(4096)
+    nnz = C.c_int64(0)
+    rc = lib.mh_lap_build_count(fake, fake, 0, None, 2 ** 30 + 5, 1000, 2.0, 0, fake, 1 << 62, fake, C.byref(nnz), None)
+    assert rc == -5 and b'int32' in lib.mh_last_error()
+    rc = lib.mh_lap_build_count(fake, fake, 0, None, 1000, 1000, 2.0, 0, fake, 16, fake, C.byref(nnz), None)
+    assert rc == -4 and b'workspace' in lib.mh_last_error()
+    rc = lib.mh_cspmm_planned(fake, fake, fake, 10, fake, 8, 4, C.c_void_p(8192), 8, 4, 1.0, None, 0, 0, 0.0, None, 0, 0, 0.0,
+                              None, 0, None, 4, fake, 3, 2, 512, fake, 1 << 20, None)
+    assert rc == -1 and b'plan' in lib.mh_last_error()

@@ -736,3 +736,69 @@ def test_recursion_entry_points_and_row_staging(small_graph):
         tgt = torch.zeros_like(x)
         lap.scatter_rows(buf, idx, tgt)
         assert torch.equal(tgt[idx.long()], x[idx.long()]) and int((tgt.abs().sum((1, 2)) > 0).sum()) == 777
+
+
+@pytest.mark.parametrize('case', ['signed_weights', 'many_duplicates', 'pow2_nodes', 'pow2_plus_one', 'two_nodes', 'dense_small'])
+def test_builder_edge_cases_vs_oracle(case):
+    _, lap, H, _, O = _mods()
+    rng = np.random.default_rng(17)
+    w = None
+    if case == 'signed_weights':          # cancellations: s = 0 or delta = 0 or d = 0 for some pairs / nodes
+        n, e = 40, 600
+        r = rng.integers(0, n, e); c = rng.integers(0, n, e)
+        w = rng.integers(-3, 4, e).astype(np.float32)
+    elif case == 'many_duplicates':       # one pair repeated 3000 times with float weights, among others
+        n = 30
+        r = np.concatenate([np.full(3000, 3), rng.integers(0, n, 200)]); c = np.concatenate([np.full(3000, 7), rng.integers(0, n, 200)])
+        w = (rng.random(len(r)) + 0.5).astype(np.float32)
+    elif case == 'pow2_nodes':
+        n, e = 1024, 20000
+        r = rng.integers(0, n, e); c = rng.integers(0, n, e); r[0], c[0] = n - 1, 0
+    elif case == 'pow2_plus_one':
+        n, e = 1025, 20000
+        r = rng.integers(0, n, e); c = rng.integers(0, n, e); r[0], c[0] = n - 1, n - 2
+    elif case == 'two_nodes':
+        n = 2
+        r = np.array([0, 0, 1]); c = np.array([1, 1, 0])
+    else:                                 # every ordered pair present once or twice
+        n = 60
+        r, c = np.nonzero(rng.random((n, n)) < 0.7)
+    if case == 'signed_weights':
+        # negative weights can make a degree negative: d^-1/2 is then NaN in the reference as well;
+        # keep degrees positive by construction so the comparison is meaningful
+        w = np.abs(w) * np.where(rng.random(len(w)) < 0.5, 1.0, 2.0).astype(np.float32)
+        w[::7] = 0.0                      # zero weights: delta == 0 and s == 0 pairs that must vanish
+    L = H.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w)
+    Lo = O.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=3e-6, what=case)
+
+
+def test_layers_accept_awkward_inputs():
+    """Non-contiguous inputs, bias=False, K=0, dropout in training mode, int32 pair indices."""
+    _, lap, H, M, O = _mods()
+    row, col, n, _ = _telegram(0.25, False)
+    L = H.hermitian_decomp_sparse_device(row, col, n, 0.25)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.25)
+    g = torch.Generator().manual_seed(2)
+    big = torch.randn(n, 12, generator=g).to(DEV)
+    Xr, Xi = big[:, ::2], big[:, 1::2]                            # strided views, 6 features each
+    conv = M.ChebConv(6, 5, 2, H.cheb_poly_sparse(L, 2), None, bias=False).to(DEV)
+    assert conv.bias is None
+    real, imag = conv((Xr, Xi))
+    rr, ri = O.cheb_conv_recursion(Lo, conv.weight.detach().cpu(), None, Xr.cpu(), Xi.cpu())
+    assert_close(real.detach().cpu().numpy(), rr.numpy()); assert_close(imag.detach().cpu().numpy(), ri.numpy())
+    conv0 = M.ChebConv(6, 5, 0, H.cheb_poly_sparse(L, 0), None).to(DEV)
+    r0, i0 = conv0((Xr, Xi))
+    assert_close(r0.detach().cpu().numpy(), (Xr.cpu() @ conv0.weight[0].detach().cpu() + conv0.bias.detach().cpu()).numpy())
+    net = M.ChebNet_Edge(6, H.cheb_poly_sparse(L, 1), None, num_filter=4, K=1, label_dim=2, activation=True, layer=2, dropout=0.5).to(DEV)
+    net.train()
+    pairs = torch.randint(0, n, (50, 2), generator=g).to(DEV)
+    out = net(Xr, Xi, pairs)
+    assert tuple(out.shape) == (50, 2) and bool(torch.isfinite(out).all())
+    out.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    mh = _mods()[0]
+    with pytest.raises(mh.MagnetHipError):
+        net(Xr, Xi, torch.tensor([[0, n]], device=DEV))           # pair index out of range
+    with pytest.raises(mh.MagnetHipError):
+        M.ChebConv(6, 5, 2, H.cheb_poly_sparse(L, 2), None)((Xr.cpu(), Xi.cpu()))
