@@ -7,8 +7,8 @@
 //   1. every input edge (i, j, w) becomes two directed 64-bit records
 //        key = row << (cb+1) | col << 1 | dir       (cb = bits of n_nodes-1)
 //      (i, j, dir=0) "forward" and (j, i, dir=1) "backward";
-//   2. one LSD radix sort over the 2*cb+1 live key bits (rocPRIM device sort; stable,
-//      so duplicate edges keep their input order);
+//   2. one stable LSD radix sort over the 2*cb+1 live key bits (radix_sort.hip: tile histograms,
+//      column scan, ballot-match ranking; duplicate edges keep their input order);
 //   3. per (row, col) segment: w_fwd, w_bwd summed in fp32 in input order,
 //      s = (w_fwd + w_bwd)/2, delta = w_fwd - w_bwd, keep = (delta != 0 && s != 0);
 //   4. degrees d_row = sum_col s (fp64 over the row's records, or half the record count
@@ -21,12 +21,13 @@
 //
 // Everything is deterministic (no atomics on data, fixed summation orders).
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "radix_sort.h"
 
 namespace {
 
@@ -58,26 +59,6 @@ int node_bits(int32_t n_nodes) {
     return cb;
 }
 
-// rocPRIM's temporary-storage query runs no kernel but needs a HIP device for its config
-// dispatch; when there is none (size queries on a CPU-only host) fall back to a bound that
-// covers its ping-pong buffers.
-size_t sort_temp_bytes(int64_t m, bool weighted, int end_bit) {
-    size_t bytes = 0;
-    hipError_t e;
-    if (weighted) {
-        e = rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const float*, float*>(
-            nullptr, bytes, nullptr, nullptr, nullptr, nullptr, size_t(m), 0u, unsigned(end_bit), hipStream_t(0));
-    } else {
-        e = rocprim::radix_sort_keys<rocprim::default_config, const uint64_t*, uint64_t*>(
-            nullptr, bytes, nullptr, nullptr, size_t(m), 0u, unsigned(end_bit), hipStream_t(0));
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        bytes = size_t(m) * (weighted ? 12 : 8) + (size_t(8) << 20);
-    }
-    return bytes + (size_t(1) << 20);   // slack: the query result may differ slightly between devices
-}
-
 Layout make_layout(int64_t n_edges, int32_t n_nodes, bool weighted, bool gcn) {
     Layout L{};
     L.e_total = n_edges + (gcn ? int64_t(n_nodes) : 0);
@@ -97,7 +78,7 @@ Layout make_layout(int64_t n_edges, int32_t n_nodes, bool weighted, bool gcn) {
     L.off_dinv = o;     o += align_up(size_t(n_nodes) * 4 + 4);
     L.off_tiles = o;    o += align_up(size_t(L.n_tiles + 1) * 4);
     L.off_sort = o;
-    L.sort_bytes = sort_temp_bytes(L.m > 0 ? L.m : 1, weighted, 2 * L.cb + 1);
+    L.sort_bytes = mhsort::workspace_bytes(L.m > 0 ? L.m : 1);
     o += align_up(L.sort_bytes);
     L.total = o;
     return L;
@@ -379,23 +360,24 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
 
     MH_HIP(hipMemsetAsync(hdr, 0, 256, stream));
     MH_HIP(hipMemsetAsync(flags, 0, size_t(L.m_pad), stream));
+    // an odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1
+    const bool start_in_0 = mhsort::passes_for(2 * L.cb + 1) & 1;
+    uint64_t* rec_keys = start_in_0 ? keys0 : keys1;
+    float* rec_w = weighted ? (start_in_0 ? w0 : w1) : nullptr;
     if (L.e_total > 0) {
         if (idx64)
             make_records<int64_t><<<grid_for(L.e_total), kBlock, 0, stream>>>(
                 static_cast<const int64_t*>(row), static_cast<const int64_t*>(col), weight, n_edges, L.e_total,
-                n_nodes, L.cb, keys0, w0, hdr);
+                n_nodes, L.cb, rec_keys, rec_w, hdr);
         else
             make_records<int32_t><<<grid_for(L.e_total), kBlock, 0, stream>>>(
                 static_cast<const int32_t*>(row), static_cast<const int32_t*>(col), weight, n_edges, L.e_total,
-                n_nodes, L.cb, keys0, w0, hdr);
+                n_nodes, L.cb, rec_keys, rec_w, hdr);
         MH_LAUNCH_CHECK("make_records");
-        size_t tb = L.sort_bytes;
-        if (weighted)
-            MH_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const float*, float*>(
-                ws + L.off_sort, tb, keys0, keys1, w0, w1, size_t(L.m), 0u, unsigned(2 * L.cb + 1), stream)));
-        else
-            MH_HIP((rocprim::radix_sort_keys<rocprim::default_config, const uint64_t*, uint64_t*>(
-                ws + L.off_sort, tb, keys0, keys1, size_t(L.m), 0u, unsigned(2 * L.cb + 1), stream)));
+        // passes alternate between the two buffers; the records were written so that the result lands in keys1
+        uint64_t* other = rec_keys == keys0 ? keys1 : keys0;
+        float* other_w = weighted ? (rec_w == w0 ? w1 : w0) : nullptr;
+        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 2 * L.cb + 1, ws + L.off_sort, L.sort_bytes, stream));
     }
     row_starts<<<grid_for(L.m + 1), kBlock, 0, stream>>>(keys1, L.m, n_nodes, L.cb, rec_ptr);
     MH_LAUNCH_CHECK("row_starts");

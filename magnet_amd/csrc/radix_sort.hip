@@ -1,0 +1,221 @@
+// Stable LSD radix sort, 8 bits per pass, for the (row, col, dir) edge records of the Laplacian
+// builder on gfx950.
+//
+// Per pass, three steps over tiles of 8192 keys (512 threads = 8 wavefronts x 16 rounds x 64 lanes):
+//   1. tile_histogram   256-bin digit histogram of every tile (LDS atomics), stored tile-major so
+//                       that a tile's 256 counters are one contiguous 1 KiB line;
+//   2. scan_*           column-wise exclusive scan of the [tiles][256] matrix in digit-major order:
+//                       chunk sums (256 tiles per chunk), one workgroup scanning the chunk sums and
+//                       the digit totals, then every chunk turning its counters into global offsets;
+//   3. scatter          each wavefront ranks its 1024 keys round by round with ballot "match" masks
+//                       (8 ballots give the lanes holding the same digit; the population count below
+//                       a lane is its rank), waves are offset against each other per digit, the tile is
+//                       laid out digit-sorted in LDS and written to global memory in runs of equal
+//                       digit.  Memory order = (wave, round, lane) = index order, so the sort is stable.
+// 2 reads + 1 write of the keys per pass; no inter-workgroup communication inside a launch.
+#include "radix_sort.h"
+
+namespace mhsort {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kItems = 16;
+constexpr int kTile = kThreads * kItems;     // 8192 keys
+constexpr int kBins = 256;
+constexpr int kChunk = 256;                  // tiles per scan chunk
+
+__device__ inline uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return uint32_t(k >> shift) & mask; }
+
+__global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                           uint32_t mask, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t bins[kBins];
+    if (threadIdx.x < kBins) bins[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = int64_t(blockIdx.x) * kTile;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        int64_t idx = base + i * kThreads + threadIdx.x;
+        if (idx < n) atomicAdd(&bins[digit_of(keys[idx], shift, mask)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) hist[int64_t(blockIdx.x) * kBins + threadIdx.x] = bins[threadIdx.x];
+}
+
+// chunk_sum[c][d] = sum over the chunk's tiles of hist[t][d]
+__global__ void __launch_bounds__(kBins) scan_chunk_sums(const uint32_t* __restrict__ hist, int64_t n_tiles,
+                                                         uint32_t* __restrict__ chunk_sum) {
+    const int d = threadIdx.x;
+    const int64_t t0 = int64_t(blockIdx.x) * kChunk;
+    const int64_t t1 = t0 + kChunk < n_tiles ? t0 + kChunk : n_tiles;
+    uint32_t s = 0;
+    for (int64_t t = t0; t < t1; ++t) s += hist[t * kBins + d];
+    chunk_sum[int64_t(blockIdx.x) * kBins + d] = s;
+}
+
+// one workgroup: chunk_sum[c][d] -> global offset of (digit d, first tile of chunk c)
+__global__ void __launch_bounds__(kBins) scan_chunks(uint32_t* __restrict__ chunk_sum, int64_t n_chunks) {
+    __shared__ uint32_t total[kBins];
+    const int d = threadIdx.x;
+    uint32_t run = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        uint32_t v = chunk_sum[c * kBins + d];
+        chunk_sum[c * kBins + d] = run;
+        run += v;
+    }
+    total[d] = run;
+    __syncthreads();
+    // exclusive scan of the 256 digit totals (Hillis-Steele in LDS)
+    uint32_t v = total[d];
+    uint32_t inc = v;
+    for (int off = 1; off < kBins; off <<= 1) {
+        uint32_t t = d >= off ? total[d - off] : 0u;
+        __syncthreads();
+        inc = total[d] + t;
+        total[d] = inc;
+        __syncthreads();
+    }
+    const uint32_t digit_base = inc - v;
+    for (int64_t c = 0; c < n_chunks; ++c) chunk_sum[c * kBins + d] += digit_base;
+}
+
+// hist[t][d] -> global offset of (digit d, tile t)
+__global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist, int64_t n_tiles,
+                                                    const uint32_t* __restrict__ chunk_off) {
+    const int d = threadIdx.x;
+    const int64_t t0 = int64_t(blockIdx.x) * kChunk;
+    const int64_t t1 = t0 + kChunk < n_tiles ? t0 + kChunk : n_tiles;
+    uint32_t run = chunk_off[int64_t(blockIdx.x) * kBins + d];
+    for (int64_t t = t0; t < t1; ++t) {
+        uint32_t v = hist[t * kBins + d];
+        hist[t * kBins + d] = run;
+        run += v;
+    }
+}
+
+template <bool PAIRS>
+__global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
+                                                    const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
+                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs) {
+    __shared__ uint32_t cnt[kWaves][kBins];
+    __shared__ uint32_t digit_start[kBins];
+    __shared__ uint32_t goff[kBins];
+    __shared__ uint64_t skeys[kTile];
+    __shared__ float svals[PAIRS ? kTile : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < kWaves * kBins; i += kThreads) (&cnt[0][0])[i] = 0;
+    if (tid < kBins) goff[tid] = offs[int64_t(blockIdx.x) * kBins + tid];
+    __syncthreads();
+
+    const int64_t tile_base = int64_t(blockIdx.x) * kTile;
+    const int64_t chunk_base = tile_base + int64_t(w) * (64 * kItems);
+    uint64_t key[kItems];
+    float val[PAIRS ? kItems : 1];
+    uint32_t rank[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        int64_t idx = chunk_base + i * 64 + lane;
+        bool ok = idx < n;
+        key[i] = ok ? kin[idx] : ~0ull;
+        if (PAIRS) val[i] = ok ? vin[idx] : 0.f;
+    }
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const bool ok = chunk_base + i * 64 + lane < n;
+        const uint32_t d = digit_of(key[i], shift, mask);
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t r = __popcll(peers & lt);
+        const uint32_t base = cnt[w][d];
+        if (ok && r == 0) cnt[w][d] = base + uint32_t(__popcll(peers));   // lowest lane of the group
+        rank[i] = base + r;
+    }
+    __syncthreads();
+    if (tid < kBins) {                     // per digit: offsets of the waves against each other, tile count
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) { uint32_t t = cnt[ww][tid]; cnt[ww][tid] = run; run += t; }
+        digit_start[tid] = run;
+    }
+    __syncthreads();
+    {                                      // exclusive scan of the 256 tile counts
+        uint32_t v = 0, inc = 0;
+        if (tid < kBins) { v = digit_start[tid]; inc = v; }
+        for (int off = 1; off < kBins; off <<= 1) {
+            uint32_t t = (tid < kBins && tid >= off) ? digit_start[tid - off] : 0u;
+            __syncthreads();
+            if (tid < kBins) { inc = digit_start[tid] + t; digit_start[tid] = inc; }
+            __syncthreads();
+        }
+        if (tid < kBins) digit_start[tid] = inc - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        if (chunk_base + i * 64 + lane < n) {
+            const uint32_t d = digit_of(key[i], shift, mask);
+            const uint32_t pos = digit_start[d] + cnt[w][d] + rank[i];
+            skeys[pos] = key[i];
+            if (PAIRS) svals[pos] = val[i];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - tile_base;
+    const int n_valid = left < kTile ? int(left) : kTile;
+    for (int j = tid; j < n_valid; j += kThreads) {
+        const uint64_t k = skeys[j];
+        const uint32_t d = digit_of(k, shift, mask);
+        const int64_t out = int64_t(goff[d]) + (j - int(digit_start[d]));
+        kout[out] = k;
+        if (PAIRS) vout[out] = svals[j];
+    }
+}
+
+inline size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+size_t workspace_bytes(int64_t n) {
+    int64_t tiles = (n + kTile - 1) / kTile;
+    if (tiles < 1) tiles = 1;
+    int64_t chunks = (tiles + kChunk - 1) / kChunk;
+    return align_up(size_t(tiles) * kBins * 4) + align_up(size_t(chunks) * kBins * 4);
+}
+
+hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int bits, void* workspace, size_t ws_bytes,
+                hipStream_t stream) {
+    if (n <= 0 || bits <= 0) return hipSuccess;
+    if (ws_bytes < workspace_bytes(n) || n >= (int64_t(1) << 32)) return hipErrorInvalidValue;
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    const int64_t chunks = (tiles + kChunk - 1) / kChunk;
+    uint32_t* hist = static_cast<uint32_t*>(workspace);
+    uint32_t* chunk = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align_up(size_t(tiles) * kBins * 4));
+    const bool pairs = va != nullptr;
+    // equal digit widths over the passes (49 key bits -> 7 passes of 7 bits): fewer bins per pass
+    // means longer runs of equal digit per tile, i.e. longer contiguous writes
+    const int width = (bits + passes_for(bits) - 1) / passes_for(bits);
+    for (int shift = 0; shift < bits; shift += width) {
+        const int nb = bits - shift < width ? bits - shift : width;
+        const uint32_t mask = (1u << nb) - 1u;
+        tile_histogram<<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist);
+        scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
+        scan_chunks<<<1, kBins, 0, stream>>>(chunk, chunks);
+        scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
+        if (pairs) scatter<true><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist);
+        else scatter<false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        uint64_t* t = a; a = b; b = t;
+        float* tv = va; va = vb; vb = tv;
+    }
+    return hipSuccess;
+}
+
+}  // namespace mhsort
