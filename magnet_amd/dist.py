@@ -299,8 +299,9 @@ class ColumnSharded:
     """Every rank holds the WHOLE Laplacian (4.8 GB at 400M nonzeros: cheap next to 288 GB) and a
     slice of the feature columns.  The K propagation orders then need no communication at all:
     column f of L X depends on column f of X only.  The per-order weight GEMM mixes columns, so
-    before it the orders are transposed from column slices to row blocks with ONE all-to-all
-    (each rank sends 1/world of what it holds to every peer).  Per conv that moves
+    before it every order is regrouped from column slices to row blocks with an all-to-all (each
+    rank sends 1/world of what it holds to every peer); the all-to-all of order k is in flight while
+    order k+1 is computed.  Per conv that moves
     (K+1) * N * 8F * (world-1)/world^2 bytes per rank, against (K-1) * N * 8F * (world-1)/world
     for the row partition on a graph without locality — (K-1) * world / (K+1) times less."""
 
@@ -311,8 +312,12 @@ class ColumnSharded:
         self.rb = [n * p // world for p in range(world)] + [n]         # output row blocks
         self.r0, self.r1 = self.rb[rank], self.rb[rank + 1]
 
-    def cheb_terms(self, x_slice, n_terms):
+    def cheb_terms(self, x_slice, n_terms, after_each=None):
+        """Column slices of [T_0 x, ..., T_{n-1} x]; `after_each(k, z)` is called as soon as order k
+        has been launched (used to start that order's regrouping while the next one computes)."""
         zs = [x_slice]
+        if after_each is not None:
+            after_each(0, x_slice)
         for k in range(1, n_terms):
             z = torch.empty_like(x_slice)
             if k == 1:
@@ -320,39 +325,44 @@ class ColumnSharded:
             else:
                 self.op.spmm(zs[k - 1], out=z, alpha=2.0, z1=zs[k - 2], beta1=-1.0)
             zs.append(z)
+            if after_each is not None:
+                after_each(k, z)
         return zs
 
-    def to_row_blocks(self, zs):
-        """[N, 2, fc] per order (my columns, all rows) -> list over source ranks p of
-        [rows_me, 2, n_terms, fc_p] (my rows, p's columns, all orders)."""
-        k1 = len(zs)
+    def start_regroup(self, z):
+        """Begin the all-to-all of ONE order: z [N, 2, fc_me] -> my rows of every rank's columns.
+        Row slices of z are contiguous, so they are sent in place.  Returns a handle for finish_regroup."""
         rows_me = self.r1 - self.r0
-        send, recv = [], []
-        for p in range(self.world):
-            send.append(torch.stack([z[self.rb[p]:self.rb[p + 1]] for z in zs], dim=2))
-            fcp = self.cb[p + 1] - self.cb[p]
-            recv.append(send[p] if p == self.rank else
-                        torch.empty((rows_me, 2, k1, fcp), dtype=zs[0].dtype, device=zs[0].device))
-        wait_all(all_to_all_blocks(send, recv, self.rank, self.world, self.group))
-        return recv
+        send = [z[self.rb[p]:self.rb[p + 1]] for p in range(self.world)]
+        recv = [send[p] if p == self.rank else
+                torch.empty((rows_me, 2, self.cb[p + 1] - self.cb[p]), dtype=z.dtype, device=z.device)
+                for p in range(self.world)]
+        return all_to_all_blocks(send, recv, self.rank, self.world, self.group), recv, z
+
+    def finish_regroup(self, handle):
+        """-> [rows_me, 2, F] (my rows, all columns) of that order."""
+        works, recv, _ = handle
+        wait_all(works)
+        return recv[0] if self.world == 1 else torch.cat(recv, dim=-1)
+
+    def to_row_blocks(self, zs):
+        """All orders at once: list over orders of [rows_me, 2, F]."""
+        return [self.finish_regroup(h) for h in [self.start_regroup(z) for z in zs]]
 
     def conv(self, x_slice, weight, bias):
-        """Rows [r0, r1) of sum_k T_k X W_k + bias, given this rank's column slice of X."""
-        k1, _, cout = weight.shape
-        zs = self.cheb_terms(x_slice, k1)
-        parts = self.to_row_blocks(zs)
+        """Rows [r0, r1) of sum_k T_k X W_k + bias, given this rank's column slice of X.  The
+        regrouping of order k travels while order k+1 is being computed."""
+        k1, cin, cout = weight.shape
+        handles = []
+        self.cheb_terms(x_slice, k1, after_each=lambda k, z: handles.append(self.start_regroup(z)))
         rows_me = self.r1 - self.r0
         out = None
-        for p, blk in enumerate(parts):
-            fcp = self.cb[p + 1] - self.cb[p]
-            if fcp == 0:
-                continue
-            wp = weight[:, self.cb[p]:self.cb[p + 1], :].reshape(k1 * fcp, cout)
-            a = blk.reshape(rows_me * 2, k1 * fcp)
+        for k, h in enumerate(handles):
+            a = self.finish_regroup(h).reshape(rows_me * 2, cin)
             if out is None:
-                out = torch.addmm(bias, a, wp) if bias is not None else torch.mm(a, wp)
+                out = torch.addmm(bias, a, weight[k]) if bias is not None else torch.mm(a, weight[k])
             else:
-                out.addmm_(a, wp)
+                out.addmm_(a, weight[k])
         return out.view(rows_me, 2, cout)
 
 
