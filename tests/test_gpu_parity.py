@@ -802,3 +802,42 @@ def test_layers_accept_awkward_inputs():
         net(Xr, Xi, torch.tensor([[0, n]], device=DEV))           # pair index out of range
     with pytest.raises(mh.MagnetHipError):
         M.ChebConv(6, 5, 2, H.cheb_poly_sparse(L, 2), None)((Xr.cpu(), Xi.cpu()))
+
+
+def test_cached_input_propagation_is_transparent():
+    """ChebNet keeps the first layer's weight-independent T_k(L) X across forwards: results equal the
+    uncached ones, an in-place change of the input or another input tensor invalidates the cache."""
+    _, lap, H, M, O = _mods()
+    row, col, n, _ = _telegram(0.25, False)
+    L = H.hermitian_decomp_sparse_device(row, col, n, 0.25)
+    torch.manual_seed(3)
+    net = M.ChebNet(6, H.cheb_poly_sparse(L, 2), None, num_filter=8, K=2, label_dim=4, activation=True, layer=2).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(n, 6, generator=g).to(DEV); Xi = torch.randn(n, 6, generator=g).to(DEV)
+    try:
+        M.ChebConv.cache_input_propagation = False
+        plain = net(X, Xi).detach().clone()
+        M.ChebConv.cache_input_propagation = True
+        a = net(X, Xi).detach().clone()           # fills the cache
+        b = net(X, Xi).detach().clone()           # served from it
+        assert torch.equal(a, plain) and torch.equal(b, plain)
+        assert net.Chebs[0]._input_cache[0] is X
+        X.mul_(2.0)                               # in place: version changes
+        c = net(X, Xi).detach().clone()
+        M.ChebConv.cache_input_propagation = False
+        assert torch.equal(c, net(X, Xi).detach())
+        M.ChebConv.cache_input_propagation = True
+        X2 = X.clone()
+        assert torch.equal(net(X2, Xi).detach(), c) and net.Chebs[0]._input_cache[0] is X2
+        # gradients flow to the weights through the cached orders, and inputs that need a gradient bypass the cache
+        net.zero_grad()
+        net(X2, Xi).sum().backward()
+        g_cached = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        Xg = X2.clone().requires_grad_(True)
+        net(Xg, Xi).sum().backward()
+        assert Xg.grad is not None
+        for p, gc in zip(net.parameters(), g_cached):
+            assert_close(p.grad.cpu().numpy(), gc.cpu().numpy(), rel=2e-5)
+    finally:
+        M.ChebConv.cache_input_propagation = True
