@@ -1,0 +1,20 @@
+"""bench.py pieces that run without a GPU."""
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_algorithmic_bytes_formula():
+    sys.path.insert(0, ROOT)
+    import bench
+    nnz, n, f = 400_000_000, 10_000_000, 256
+    # CSR once (12 B per nonzero + row_ptr) + one gathered 2 KiB row per nonzero + one output row per node
+    assert bench.algorithmic_bytes(nnz, n, f, 0) == nnz * 12 + 4 * (n + 1) + nnz * 2048 + n * 2048
+    assert bench.algorithmic_bytes(nnz, n, f, 1) - bench.algorithmic_bytes(nnz, n, f, 0) == n * 2048
+    assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_bench_help_runs_without_gpu():
+    out = subprocess.run([sys.executable, 'bench.py', '--help'], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and '--gpus' in out.stdout and '--strategy' in out.stdout
