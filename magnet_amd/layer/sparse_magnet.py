@@ -117,22 +117,27 @@ def _cheb_terms(lap, x0, n_terms):
     return zs
 
 
-def _clenshaw(lap, ys, bias=None, relu=False):
-    """sum_k T_k(L) ys[k] by Clenshaw's recurrence (K SpMMs); bias / complex ReLU fused into the
-    last SpMM.  Returns (result, mask)."""
-    n_terms = len(ys)
-    n, _, f = ys[0].shape
-    mask = torch.empty((n, f), dtype=torch.uint8, device=ys[0].device) if relu else None
+def _clenshaw(lap, ys, bias=None, relu=False, n_terms=None):
+    """sum_k T_k(L) y_k by Clenshaw's recurrence (K SpMMs); bias / complex ReLU fused into the
+    last SpMM.  `ys` is a list, or a callable k -> y_k with `n_terms` given (each y_k is then made
+    only when the recurrence reaches it, and dropped right after).  Returns (result, mask)."""
+    get = ys if callable(ys) else (lambda k: ys[k])
+    if n_terms is None:
+        n_terms = len(ys)
+    y_last = get(n_terms - 1)
+    n, _, f = y_last.shape
+    mask = torch.empty((n, f), dtype=torch.uint8, device=y_last.device) if relu else None
     if n_terms == 1:
-        out = ys[0].clone(memory_format=torch.contiguous_format)
+        out = y_last.clone(memory_format=torch.contiguous_format)
         m = _bias_relu_(out, bias, relu)
         return out, m
     b2 = None                     # b_{k+2}
-    b1 = ys[n_terms - 1]          # b_{k+1}, starts as b_K = y_K
+    b1 = y_last                   # b_{k+1}, starts as b_K = y_K
+    y_last = None
     for k in range(n_terms - 2, 0, -1):
-        nb = lap.spmm(b1, alpha=2.0, z1=ys[k], beta1=1.0, z2=b2, beta2=-1.0)
+        nb = lap.spmm(b1, alpha=2.0, z1=get(k), beta1=1.0, z2=b2, beta2=-1.0)
         b2, b1 = b1, nb
-    out = lap.spmm(b1, alpha=1.0, z1=ys[0], beta1=1.0, z2=b2, beta2=-1.0, bias=bias, relu=relu, mask=mask)
+    out = lap.spmm(b1, alpha=1.0, z1=get(0), beta1=1.0, z2=b2, beta2=-1.0, bias=bias, relu=relu, mask=mask)
     return out, mask
 
 
@@ -199,9 +204,10 @@ class _ChebConvFn(torch.autograd.Function):
         else:
             if need_w:
                 dw = torch.stack([_gram(_rows2(z), g2) for z in ctx.zs])
+            ctx.zs = None                                  # the saved orders are not needed past this point
             if need_x:
-                hs = [torch.mm(g2, w[k].t()).view(n, 2, cin) for k in range(k1)]
-                dx, _ = _clenshaw(lap, hs)
+                # G W_k^T is formed when the recurrence reaches order k, not for all orders up front
+                dx, _ = _clenshaw(lap, lambda k: torch.mm(g2, w[k].t()).view(n, 2, cin), n_terms=k1)
         return dx, dw, db, None, None, None
 
 
