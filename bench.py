@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument('--strategy', choices=['auto', 'rows', 'cols'], default='auto',
                    help='multi-GPU decomposition (see magnet_amd/dist.py)')
     p.add_argument('--force-dist', action='store_true', help='take the multi-GPU code path even with one rank (rehearsal)')
+    p.add_argument('--relabel', action='store_true',
+                   help='apply a random vertex relabelling (seed 99) to the generated graph: the locality-free stress variant')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-epoch', action='store_true', help='skip the secondary epoch-time measurement')
     p.add_argument('--cpu-sample-nodes', type=int, default=250_000)
@@ -60,6 +62,28 @@ def algorithmic_bytes(nnz, n_rows, f, n_addends):
     nonzero, one output row per node, one more row read per axpy addend."""
     row_bytes = 8 * f
     return nnz * 12 + 4 * (n_rows + 1) + nnz * row_bytes + n_rows * row_bytes * (1 + n_addends)
+
+
+def stream_ceilings(dev, nbytes=8 << 30, iters=5):
+    """Measured streaming ceilings of this device in GB/s: a device-to-device copy of nbytes (torch,
+    read + write counted) and a read-only pass over the same buffer (mh_stream_read).  Reported
+    beside the spec peak: the SpMM is read-dominated, so the read-only figure is the one it can approach."""
+    from magnet_amd import _lib
+    a = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+    sink = torch.zeros(1, device=dev)
+    stream = _lib.stream_ptr(dev)
+    read = lambda: _lib.check(_lib.lib.mh_stream_read(_lib.ptr(a), nbytes, _lib.ptr(sink), stream))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    b.copy_(a); read()
+    ev[0].record()
+    for _ in range(iters):
+        b.copy_(a)
+    ev[1].record()
+    for _ in range(iters):
+        read()
+    ev[2].record(); torch.cuda.synchronize()
+    return {'copy': 2.0 * nbytes * iters / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9,
+            'read': 1.0 * nbytes * iters / (ev[1].elapsed_time(ev[2]) * 1e-3) / 1e9}
 
 
 def cpu_baseline(args):
@@ -196,6 +220,10 @@ def main():
 
     n, e, f, K = args.nodes, args.edges, args.features, args.K
     src, dst = powerlaw_edges(n, e, args.seed, device=dev)
+    if args.relabel:
+        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
+        src, dst = perm[src], perm[dst]
+        del perm
     torch.cuda.synchronize()
     t0 = time.time()
     lap = build_magnetic_laplacian(src, dst, n, q=args.q)
@@ -270,6 +298,8 @@ def main():
         except Exception:
             traffic = None
 
+    ceiling = stream_ceilings(dev) if rank == 0 else None
+
     epoch = None
     if not args.no_epoch:
         del step, launches
@@ -288,7 +318,8 @@ def main():
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': 'power-law digraph N=%d E=%d (seed %d), %d complex features, K=%d, q=%g; step = one '
-                            'MagNetConv forward (K fused complex SpMM orders + K+1 weight GEMMs + bias)' % (n, e, args.seed, f, K, args.q),
+                            'MagNetConv forward (K fused complex SpMM orders + K+1 weight GEMMs + bias)%s' % (
+                                n, e, args.seed, f, K, args.q, '; vertices randomly relabelled (seed 99)' if args.relabel else ''),
                 'nnz': nnz_total, 'parallelism': '%s%d' % (strategy, world) if multi else 'single',
             },
             'roofline': {
@@ -296,6 +327,8 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'kernel': 'cspmm_vec4 (fused complex CSR SpMM)', 'launches': n_launches_total,
                 'avg_launch_ms': k_ms / n_launch, 'algorithmic_bytes_per_launch': k_bytes / n_launch,
+                'measured_stream_ceilings': ceiling,
+                'frac_of_measured_read_ceiling': achieved / ceiling['read'] if ceiling else None,
             },
             'spmm_edges_per_s': nnz_total * K * args.steps / (k_ms * 1e-3) if k_ms > 0 and world == 1 else None,
             'input_edges_per_s': e * K / (elapsed / args.steps),

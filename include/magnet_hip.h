@@ -186,6 +186,15 @@ int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask,
 int mh_powerlaw_edges(int32_t n_nodes, int64_t n_edges, uint64_t seed, int64_t first_edge,
                       int32_t* src, int32_t* dst, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): one read-only pass over `bytes`
+ * bytes of device memory (16-byte aligned), 16-byte loads, nothing written
+ * (`sink` is one float that is only a formal destination).  Timing it gives the
+ * streaming-read ceiling of the device that the gather-bound SpMM is compared
+ * with next to the 8 TB/s specification figure.
+ */
+int mh_stream_read(const void* buf, size_t bytes, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,8 @@ def _load():
     lib.mh_relu_bwd.argtypes = [vp, i64, i64, vp, i64, i32, vp]
     lib.mh_powerlaw_edges.restype = C.c_int
     lib.mh_powerlaw_edges.argtypes = [i32, i64, u64, i64, vp, vp, vp]
+    lib.mh_stream_read.restype = C.c_int
+    lib.mh_stream_read.argtypes = [vp, sz, vp, vp]
     return lib
 
 
@@ -73,7 +75,7 @@ lib = _load()
 
 EXPORTS = ['mh_version', 'mh_last_error', 'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
            'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill', 'mh_cheb_terms', 'mh_clenshaw', 'mh_unpack', 'mh_gather_rows',
-           'mh_scatter_rows', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges']
+           'mh_scatter_rows', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges', 'mh_stream_read']
 
 
 def check(rc):
