@@ -211,7 +211,9 @@ def main():
     import torch.distributed as dist
     multi = world > 1 or args.force_dist
     if multi:
-        dist.init_process_group('nccl', device_id=dev)
+        import datetime
+        # a collective that cannot complete ends the run after 5 minutes instead of the 10-minute default
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=5))
 
     from magnet_amd import laplacian as lapmod
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges

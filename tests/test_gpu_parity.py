@@ -566,6 +566,18 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (1, 4) and res[0, 1] >= 0.9, res
     res = drv.run(['-D', '--dataset', 'syn/cyclic', '--q', '0.1', '--K', '1', '--splits', '1', '--log_root', str(tmp_path) + '/'])
     assert res.shape == (1, 4)
+    # --hip_graph replays the same epochs: the logged losses follow the eager run from epoch 0 on
+    import glob, re
+    logs = {}
+    for tag, extra in (('eager', []), ('graph', ['--hip_graph'])):
+        root = '%s/%s/' % (tmp_path, tag)
+        drv.run(['--dataset', 'syn/cyclic', '--p_q', '0.95', '--seed', '10', '--q', '0.1', '--K', '2', '-a', '--num_filter', '16',
+                 '--layer', '2', '--epochs', '25', '--splits', '1', '--log_root', root, '--randomseed', '1'] + extra)
+        text = open(glob.glob(root + '**/log0.csv', recursive=True)[0]).read()
+        logs[tag] = np.array([[float(a), float(b)] for a, b in
+                              re.findall(r'Train loss:, ([0-9.]+),.*? Test loss:, ([0-9.]+),', text)])
+    assert logs['eager'].shape == (25, 2) and logs['graph'].shape == (25, 2)
+    assert np.abs(logs['eager'] - logs['graph']).max() <= 2e-4, np.abs(logs['eager'] - logs['graph']).max()
 
 
 def test_link_driver_runs_all_tasks(tmp_path):
