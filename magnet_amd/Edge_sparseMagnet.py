@@ -51,6 +51,15 @@ def parse_args(argv=None):
     return parser.parse_args(argv)
 
 
+def sparse_mx_to_torch_sparse_tensor(sparse_mx):
+    """scipy sparse matrix -> float32 torch sparse COO tensor with int64 indices, in scipy's entry
+    order and not coalesced (reference src/Edge_sparseMagnet.py:63-70).  Only needed by callers that still hand
+    the layers the reference's two lists of K+1 tensors; the drivers here pass the ChebBasis."""
+    coo = sparse_mx.tocoo().astype(np.float32)
+    idx = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data), torch.Size(coo.shape))
+
+
 def load_graph(args):
     head = args.dataset.split('/')[0]
     if head == 'syn':
@@ -143,7 +152,12 @@ def run(argv=None):
     args.save_name = args.method_name + 'lr' + str(int(args.lr * 1000)) + 'num_filters' + str(int(args.num_filter)) + \
         'q' + str(int(100 * args.q)) + 'task' + str(int(args.task)) + 'link' + str(int(args.num_class_link))
     args.log_path = os.path.join(args.log_path, args.method_name, args.dataset)
-    return main(args)
+    # reference src/Edge_sparseMagnet.py:317-327; kept beside the logs (<src>/../result_arrays next to ../logs)
+    dir_name = os.path.join(args.log_root, '..', 'result_arrays', args.log_path, args.dataset + '/')
+    results = main(args)
+    os.makedirs(dir_name, exist_ok=True)
+    np.save(dir_name + args.save_name, results)
+    return results
 
 
 if __name__ == "__main__":

@@ -75,6 +75,47 @@ def dsbm_cyclic(n_per_cluster=500, clusters=5, p_in=0.1, p_inter=0.1, p_q=0.95, 
                      train_mask=tr, val_mask=va, test_mask=te)
 
 
+def dsbm(meta='ordered', n_per_cluster=500, clusters=5, p_in=0.1, p_inter=0.1, p_q=0.95, seed=0, train_per_class=10):
+    """Directed stochastic block model with the reference's three meta-graphs
+    (src/utils/generate_cyclic.py:79-143, src/utils/generate_fill.py:6-78):
+
+      'ordered' — every pair of clusters a < b is linked with probability p_inter and an edge points
+                  a -> b with probability p_q (the syn/syn* family, cycle=False);
+      'cyclic'  — only clusters adjacent on the cycle 0 -> 1 -> ... -> c-1 -> 0 are linked, edges
+                  point along the cycle with probability p_q (cycle=True);
+      'fill'    — as 'cyclic', and the other cluster pairs are linked too, with a uniformly random
+                  direction (cycle=True, fill=True).
+    Inside a cluster (probability p_in) directions are uniformly random.  Features N(0,1) [N,1]."""
+    if meta not in ('ordered', 'cyclic', 'fill'):
+        raise ValueError('meta must be ordered, cyclic or fill')
+    if meta == 'cyclic':
+        return dsbm_cyclic(n_per_cluster, clusters, p_in, p_inter, p_q, seed, train_per_class)
+    rng = np.random.default_rng(seed)
+    m = n_per_cluster
+    src, dst = [], []
+    for a in range(clusters):
+        x, y = np.nonzero(np.triu(rng.random((m, m)) < p_in, 1))
+        flip = rng.random(len(x)) < 0.5
+        src.append(np.where(flip, y, x) + a * m); dst.append(np.where(flip, x, y) + a * m)
+        for b in range(a + 1, clusters):
+            if meta == 'ordered' or b == a + 1:
+                p_ab = p_q                                  # a -> b
+            elif a == 0 and b == clusters - 1:
+                p_ab = 1.0 - p_q                            # closing arc of the cycle: b -> a
+            else:
+                p_ab = 0.5                                  # 'fill': undirected noise between non-adjacent clusters
+            x, y = np.nonzero(rng.random((m, m)) < p_inter)
+            fwd = rng.random(len(x)) < p_ab
+            src.append(np.where(fwd, x + a * m, y + b * m)); dst.append(np.where(fwd, y + b * m, x + a * m))
+    n = m * clusters
+    edge_index = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
+    y = np.repeat(np.arange(clusters), m)
+    x = torch.from_numpy(rng.normal(0, 1.0, (n, 1)).astype(np.float32))
+    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500, seed=seed)
+    return GraphData(x=x, edge_index=edge_index, edge_weight=None, y=torch.from_numpy(y).long(),
+                     train_mask=tr, val_mask=va, test_mask=te)
+
+
 def load_npz_citation(path, n_splits=10):
     """`.npz` citation graphs (cora_ml, citeseer_npz; reference src/utils/Citation.py:36-73,96-110):
     adjacency, dense features, labels, 20-per-class / 500 / rest splits.  allow_pickle stays off."""

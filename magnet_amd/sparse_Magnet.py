@@ -48,17 +48,97 @@ def parse_args(argv=None):
     parser.add_argument('--num_filter', type=int, default=1)
     parser.add_argument('--randomseed', type=int, default=-1)
     parser.add_argument('--splits', type=int, default=10, help='how many of the 10 splits to run')
+    parser.add_argument('--settings_dir', type=str, default='.',
+                        help='where the saved best-setting dictionaries (syn_settings.pk, Cyclic_setting_dict.pk, '
+                             'Cyclic_fill_setting_dict.pk) live; the reference opens them in the working directory')
     parser.add_argument('--hip_graph', action='store_true',
                         help='(not in the reference) capture the epoch once and replay it as one HIP graph: the '
                              'small datasets spend their epoch in launch overhead')
     return parser.parse_args(argv)
 
 
+def sparse_mx_to_torch_sparse_tensor(sparse_mx):
+    """scipy sparse matrix -> float32 torch sparse COO tensor with int64 indices, in scipy's entry
+    order and not coalesced (reference src/sparse_Magnet.py:55-62).  Only needed by callers that still hand
+    the layers the reference's two lists of K+1 tensors; the drivers here pass the ChebBasis."""
+    coo = sparse_mx.tocoo().astype(np.float32)
+    idx = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data), torch.Size(coo.shape))
+
+
+def syn_kind(dataset):
+    """Meta-graph family of a syn/... dataset name (reference src/sparse_Magnet.py:245-258)."""
+    tail = dataset[4:]
+    return 'ordered' if tail[:3] == 'syn' else 'cyclic' if tail[:6] == 'cyclic' else 'fill'
+
+
+def rename_syn_dataset(args):
+    """syn/<family> -> the reference's file stem with p_q and the seed in it
+    (src/sparse_Magnet.py:245-258); the negative p_q codes select the p_inter = 0.08 / 0.05 variants."""
+    if args.dataset[:3] != 'syn':
+        return
+    kind = syn_kind(args.dataset)
+    args.gen_p_q = 0.95 if args.p_q in (-0.08, -0.05) else args.p_q      # the coded variants are p_q = 0.95 graphs
+    if kind == 'ordered':
+        if args.p_q == -0.08:
+            args.p_inter = 0.08
+            args.dataset = 'syn/syn2Seed' + str(args.seed)
+        elif args.p_q == -0.05:
+            args.p_inter = 0.05
+            args.dataset = 'syn/syn3Seed' + str(args.seed)
+        else:
+            args.dataset = 'syn/syn' + str(int(100 * args.p_q)) + 'Seed' + str(args.seed)
+    else:
+        args.dataset = 'syn/' + kind + str(int(100 * args.p_q)) + 'Seed' + str(args.seed)
+
+
+def apply_saved_settings(args):
+    """Without --new_setting the reference replaces num_filter / layer / K / lr / q by the best setting it
+    saved for the dataset and method (src/sparse_Magnet.py:262-303).  The dictionaries are pickles of
+    plain strings; they are read by walking the opcodes, never unpickled.  A missing file, dataset or
+    method leaves the command-line values in force (the reference would stop with an exception)."""
+    if args.new_setting or args.dataset[:3] != 'syn':
+        return False
+    from .utils.inert_pickle import load_inert
+    kind = syn_kind(args.dataset)
+    try:
+        if kind == 'ordered':
+            fname = 'syn_settings.pk'
+            if args.p_inter == 0.1:
+                key = 'syn/syn' + str({0.95: 1, 0.9: 4, 0.85: 5, 0.8: 6, 0.75: 7, 0.7: 8, 0.65: 9, 0.6: 10}[args.p_q])
+            elif args.p_inter in (0.08, 0.05):
+                key = 'syn/syn2' if args.p_inter == 0.08 else 'syn/syn3'
+            else:
+                raise ValueError('Please input the correct p_q and p_inter values!')
+        elif kind == 'cyclic':
+            fname = 'Cyclic_setting_dict.pk'
+            key = 'syn/syn_tri_' + str({0.95: 0, 0.9: 1, 0.85: 2, 0.8: 3, 0.75: 4, 0.7: 5, 0.65: 6}[args.p_q])
+        else:
+            fname = 'Cyclic_fill_setting_dict.pk'
+            key = 'syn/syn_tri_' + str({0.95: 0, 0.9: 1, 0.85: 2, 0.8: 3}[args.p_q]) + '_fill'
+        path = os.path.join(args.settings_dir, fname)
+        if not os.path.exists(path):
+            return False
+        table = load_inert(open(path, 'rb').read())
+        cur = table[key][args.method_name].split(',')
+    except (KeyError, TypeError):
+        return False
+    for name, cast in (('num_filter', int), ('layer', int), ('K', int)):
+        if name in cur:
+            setattr(args, name, cast(cur[cur.index(name) + 1]))
+    args.lr = float(cur[cur.index('lr') + 1])
+    args.q = float(cur[cur.index('q') + 1])
+    return True
+
+
 def make_loader(args):
     """callable(root=..., name=...) -> [GraphData], the `dataset` argument of geometric_dataset_sparse."""
     head = args.dataset.split('/')[0]
     if head == 'syn':
-        return lambda root, name=None: [D.dsbm_cyclic(p_inter=args.p_inter, p_q=args.p_q, seed=args.seed)]
+        kind = syn_kind(args.dataset)
+        per_class = {'ordered': 10, 'cyclic': 50, 'fill': 50}[kind]       # as the reference's generators
+        return lambda root, name=None: [D.dsbm(kind, p_inter=args.p_inter, p_q=getattr(args, 'gen_p_q', args.p_q), seed=args.seed,
+                                               train_per_class=per_class)]
     if head == 'telegram':
         return lambda root, name=None: [D.load_telegram(os.path.dirname(os.path.normpath(root)))]
     if head in ('cora_ml', 'citeseer_npz'):
@@ -153,10 +233,17 @@ def run(argv=None):
     args = parse_args(argv)
     if args.debug:
         args.epochs = 1
+    rename_syn_dataset(args)
+    # the reference keeps result arrays beside its logs: <src>/../result_arrays next to the default ../logs
+    dir_name = os.path.join(args.log_root, '..', 'result_arrays', args.log_path, args.dataset + '/')
     args.log_path = os.path.join(args.log_path, args.method_name, args.dataset)
+    apply_saved_settings(args)
     args.save_name = args.method_name + 'lr' + str(int(args.lr * 1000)) + 'num_filters' + str(int(args.num_filter)) + \
         'q' + str(int(100 * args.q)) + 'layer' + str(int(args.layer))
-    return main(args)
+    results = main(args)
+    os.makedirs(dir_name, exist_ok=True)
+    np.save(dir_name + args.save_name, results)
+    return results
 
 
 if __name__ == "__main__":

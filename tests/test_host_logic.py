@@ -90,3 +90,66 @@ def test_link_split_generation(tmp_path):
     # existence task: two balanced classes
     p, l = undirected_label2directed_label(A, ds[0]['test']['pairs'], task=1)
     assert set(np.unique(l)) <= {0, 1} and abs(int((l == 0).sum()) - int((l == 1).sum())) <= 1
+
+
+def test_dsbm_meta_graphs():
+    """The three meta-graph families of the reference's DSBM generators: which cluster pairs are
+    linked and which way their edges point."""
+    from magnet_amd import data as D
+    m, c = 60, 5
+    for meta in ('ordered', 'cyclic', 'fill'):
+        g = D.dsbm(meta, n_per_cluster=m, clusters=c, p_in=0.2, p_inter=0.2, p_q=0.9, seed=3, train_per_class=5)
+        src, dst = g.edge_index.numpy()
+        assert g.x.shape == (m * c, 1) and src.max() < m * c and (src != dst).all()
+        cnt = np.zeros((c, c), np.int64)
+        np.add.at(cnt, (src // m, dst // m), 1)
+        for a in range(c):
+            for b in range(a + 1, c):
+                tot, fwd = cnt[a, b] + cnt[b, a], cnt[a, b]
+                closing = a == 0 and b == c - 1
+                if meta == 'ordered' or b == a + 1:
+                    assert tot > 0 and fwd / tot > 0.8
+                elif closing:
+                    assert tot > 0 and fwd / tot < 0.2           # last cluster -> first
+                elif meta == 'fill':
+                    assert tot > 0 and 0.35 < fwd / tot < 0.65
+                else:
+                    assert tot == 0
+        a = D.dsbm(meta, n_per_cluster=m, clusters=c, seed=3).edge_index
+        b = D.dsbm(meta, n_per_cluster=m, clusters=c, seed=3).edge_index
+        assert torch.equal(a, b)                                  # seeded
+
+
+def test_driver_dataset_names_and_saved_settings(tmp_path):
+    """Dataset renaming and the best-setting override of the node driver
+    (reference src/sparse_Magnet.py:245-303); the dictionaries are read without unpickling."""
+    import pickle
+    from magnet_amd import sparse_Magnet as drv
+    args = drv.parse_args(['--dataset', 'syn/cyclic', '--p_q', '0.9', '--seed', '20', '--settings_dir', str(tmp_path)])
+    drv.rename_syn_dataset(args)
+    assert args.dataset == 'syn/cyclic90Seed20' and drv.syn_kind(args.dataset) == 'cyclic'
+    assert drv.apply_saved_settings(args) is False and args.K == 2           # no file: command line stays
+    table = {'syn/syn_tri_1': {'Magnet': 'log_root,../logs/,dataset,syn/syn_tri_1,epochs,3000,q,0.05,seed,0,K,1,layer,3,'
+                                         'dropout,0.5,lr,0.01,l2,0.0005,activation,True,num_filter,16,,val_acc,0.9',
+                               'GCN': 'lr,0.001'}}
+    with open(tmp_path / 'Cyclic_setting_dict.pk', 'wb') as f:
+        pickle.dump(table, f)
+    assert drv.apply_saved_settings(args) is True
+    assert (args.K, args.layer, args.num_filter, args.lr, args.q) == (1, 3, 16, 0.01, 0.05)
+    a2 = drv.parse_args(['--dataset', 'syn/cyclic', '--p_q', '0.9', '-NS', '--settings_dir', str(tmp_path)])
+    drv.rename_syn_dataset(a2)
+    assert drv.apply_saved_settings(a2) is False and a2.lr == 5e-3            # -NS keeps the command line
+    a3 = drv.parse_args(['--dataset', 'syn/syn', '--p_q', '-0.08', '--seed', '0'])
+    drv.rename_syn_dataset(a3)
+    assert a3.dataset == 'syn/syn2Seed0' and a3.p_inter == 0.08 and a3.gen_p_q == 0.95
+    a4 = drv.parse_args(['--dataset', 'syn/fill', '--p_q', '0.8', '--seed', '5'])
+    drv.rename_syn_dataset(a4)
+    assert a4.dataset == 'syn/fill80Seed5' and drv.syn_kind(a4.dataset) == 'fill'
+    # the reference's own dictionary, when the reference tree is present (build container only)
+    ref = '/root/reference/src'
+    import os
+    if os.path.exists(os.path.join(ref, 'Cyclic_setting_dict.pk')):
+        a5 = drv.parse_args(['--dataset', 'syn/cyclic', '--p_q', '0.95', '--settings_dir', ref])
+        drv.rename_syn_dataset(a5)
+        assert drv.apply_saved_settings(a5) is True
+        assert (a5.K, a5.layer, a5.num_filter, a5.lr, a5.q) == (1, 3, 16, 0.01, 0.05)
