@@ -208,7 +208,7 @@ __device__ inline void epilogue(const SpmmArgs& a, int r, int64_t foff, float4 a
 template <int LPN, int CH, int UNROLL, bool NT>
 __global__ void __launch_bounds__(kBlock) cspmm_vec4(const SpmmArgs a) {
     const Lanes<LPN, CH> L(a.F);
-    const int wave0 = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
+    const int wave0 = __builtin_amdgcn_readfirstlane(int(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int r = wave0; r < a.n_rows; r += n_waves) {
         const int start = a.row_ptr[r], end = a.row_ptr[r + 1];
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_vec4(const SpmmArgs a) {
 template <int LPN, int CH, int UNROLL, bool NT>
 __global__ void __launch_bounds__(kBlock) cspmm_vec4_chunks(const SpmmArgs a) {
     const Lanes<LPN, CH> L(a.F);
-    const int c0 = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
+    const int c0 = __builtin_amdgcn_readfirstlane(int(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
     if (c0 >= a.n_chunks) return;
     const int li = a.chunk_long[c0];
     const int r = a.long_row[li];
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_vec4_chunks(const SpmmArgs a) {
 // one wave per long row: partials added in chunk order, then the epilogue
 __global__ void __launch_bounds__(kBlock) cspmm_vec4_combine(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
-    const int li = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
+    const int li = __builtin_amdgcn_readfirstlane(int(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
     if (li >= a.n_long) return;
     const int r = a.long_row[li], base = a.long_base[li], cnt = a.long_cnt[li];
     const int nvec = a.F >> 2;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_scalar(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int lg = lane & (LPN - 1);
     const int g = lane / LPN;
-    const int wave0 = __builtin_amdgcn_readfirstlane(int((blockIdx.x * kBlock + threadIdx.x) >> 6));
+    const int wave0 = __builtin_amdgcn_readfirstlane(int(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int r = wave0; r < a.n_rows; r += n_waves) {
         const int start = a.row_ptr[r], end = a.row_ptr[r + 1];
@@ -360,21 +360,21 @@ unsigned spmm_grid(int32_t n_rows) {
     return unsigned((cap == 0 || want < cap) ? want : cap);
 }
 
-bool use_nt(const SpmmArgs& a) {
-    static int mode = -1;                           // tuning knob: MH_SPMM_NT = 0 | 1 | auto (default)
+bool use_nt() {
+    // tuning knob: MH_SPMM_NT=1 gathers feature rows with non-temporal loads.  Off by default: it was
+    // measured slightly slower at 10M nodes and much slower whenever hot rows fit the caches.
+    static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("MH_SPMM_NT");
-        mode = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
+        mode = (e && e[0] == '1') ? 1 : 0;
     }
-    if (mode != 2) return mode == 1;
-    // feature matrix far larger than the 256 MiB Infinity Cache: gathered rows are not worth caching
-    return false;
+    return mode == 1;
 }
 
 template <int LPN, int CH, int UNROLL>
 void launch_vec(const SpmmArgs& a, hipStream_t s) {
     const unsigned g_chunks = unsigned((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (use_nt(a)) {
+    if (use_nt()) {
         cspmm_vec4<LPN, CH, UNROLL, true><<<spmm_grid(a.n_rows), kBlock, 0, s>>>(a);
         if (a.n_long > 0) cspmm_vec4_chunks<LPN, CH, UNROLL, true><<<g_chunks, kBlock, 0, s>>>(a);
     } else {

@@ -286,7 +286,8 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
                                                        const uint32_t* __restrict__ pos, const float* __restrict__ seg_s,
                                                        const float* __restrict__ seg_d, const float* __restrict__ dinv,
                                                        int64_t m, int cb, float two_pi_q, float scale, int diag,
-                                                       int32_t* __restrict__ col_idx, float2* __restrict__ val) {
+                                                       int64_t nnz, int32_t* __restrict__ col_idx,
+                                                       float2* __restrict__ val) {
     int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= m || !flags[p]) return;
     uint64_t k = keys[p];
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
     int32_t c = int32_t((k >> 1) & ((1ull << cb) - 1ull));
     int64_t idx = int64_t(pos[p]);
     if (diag) idx += int64_t(r) + (c > r ? 1 : 0);
+    if (idx >= nnz) return;                            // caller's arrays are shorter than the count phase reported
     float a = (dinv[r] * seg_s[p]) * dinv[c];          // (D A_s) D, hermitian.py:154
     float theta = two_pi_q * seg_d[p];                 // fp32 product, hermitian.py:157
     float sn, cs;
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
 
 // diagonal (2/lmax - 1) of every row; its slot follows the row's kept entries with col < r
 __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
-                                                        int64_t m, int32_t n_nodes, int cb, float diag_val,
+                                                        int64_t m, int32_t n_nodes, int cb, float diag_val, int64_t nnz,
                                                         int32_t* __restrict__ col_idx, float2* __restrict__ val) {
     int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (r >= n_nodes) return;
@@ -316,6 +318,7 @@ __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restri
         if (keys[mid] < target) lo = mid + 1; else hi = mid;
     }
     int64_t idx = int64_t(pos[lo]) + r;
+    if (idx >= nnz) return;
     col_idx[idx] = int32_t(r);
     val[idx] = make_float2(diag_val, 0.0f);
 }
@@ -438,12 +441,12 @@ extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, float q, floa
         MH_REQUIRE(col_idx && val, "col_idx/val is null");
         MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
         emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(keys1, flags, pos, seg_s, seg_d, dinv, L.m, L.cb, two_pi_q,
-                                                           scale, diag, col_idx, reinterpret_cast<float2*>(val));
+                                                           scale, diag, nnz, col_idx, reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_entries");
     }
     if (diag && n_nodes > 0) {
         MH_REQUIRE(col_idx && val && nnz >= n_nodes, "col_idx/val is null or nnz too small for the diagonal");
-        emit_diagonal<<<grid_for(n_nodes), kBlock, 0, stream>>>(keys1, pos, L.m, n_nodes, L.cb, diag_val, col_idx,
+        emit_diagonal<<<grid_for(n_nodes), kBlock, 0, stream>>>(keys1, pos, L.m, n_nodes, L.cb, diag_val, nnz, col_idx,
                                                                 reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_diagonal");
     }

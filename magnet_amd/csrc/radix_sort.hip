@@ -1,4 +1,4 @@
-// Stable LSD radix sort, 8 bits per pass, for the (row, col, dir) edge records of the Laplacian
+// Stable LSD radix sort, at most 8 bits per pass (the key bits are spread evenly over the passes), for the (row, col, dir) edge records of the Laplacian
 // builder on gfx950.
 //
 // Per pass, three steps over tiles of 8192 keys (512 threads = 8 wavefronts x 16 rounds x 64 lanes):
