@@ -254,12 +254,16 @@ def main():
         launches = layer.launches
     else:
         conv = ChebConv(f, f, K, ChebBasis(lap, K), None).to(dev)
-        xp = torch.randn(n, 2, f, device=dev)
+        # features resident in the layout a conv inside a network receives them in: order 0 of the
+        # [N, 2, K+1, F] block whose other orders the conv fills (the layer before writes them there)
+        block = torch.empty(n, 2, K + 1, f, device=dev)
+        xp = block[:, :, 0, :]
+        xp.normal_()
         launches = []
 
         def step():
             with torch.no_grad():
-                return conv.forward_packed(xp)
+                return conv.forward_packed(xp, in_block=block)
 
     def observer(ev0, ev1, info):
         launches.append((ev0, ev1, info))
@@ -305,7 +309,7 @@ def main():
     epoch = None
     if not args.no_epoch:
         del step, launches
-        layer = conv = xp = lap = None
+        layer = conv = xp = block = lap = None
         torch.cuda.empty_cache()
         try:
             epoch = epoch_time(rank, world, dev, multi)
