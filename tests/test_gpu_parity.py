@@ -853,3 +853,51 @@ def test_cached_input_propagation_is_transparent():
             assert_close(p.grad.cpu().numpy(), gc.cpu().numpy(), rel=2e-5)
     finally:
         M.ChebConv.cache_input_propagation = True
+
+
+def test_trunk_hand_over_of_order_blocks():
+    """Inside a network a conv writes its output where the next conv wants its order 0 (one block
+    [N, 2, K+1, F] per conv, one GEMM over it).  A trunk with changing widths and orders, SpMM-first and
+    GEMM-first layers, fused and unfused ReLUs must give what the layers give when called one by one
+    through the reference's (real, imag) interface, and the oracle's numbers."""
+    _, lap, H, M, O = _mods()
+    row, col, n, w = _telegram(0.25, True)
+    L = H.hermitian_decomp_sparse_device(row, col, n, 0.25, edge_weight=w)
+    Ls = O.hermitian_decomp_sparse(row, col, n, 0.25, edge_weight=w)
+    torch.manual_seed(11)
+    dims = [(5, 8, 3), (8, 8, 1), (8, 12, 2), (12, 4, 3), (4, 6, 2)]      # (in, out, K); 12 -> 4 is GEMM-first
+    mods = []
+    for i, (a, b, k) in enumerate(dims):
+        mods.append(M.ChebConv(a, b, k, H.cheb_poly_sparse(L, k), None))
+        if i != 1:
+            mods.append(M.complex_relu_layer())
+    chebs = torch.nn.Sequential(*mods).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    Xr = torch.randn(n, 5, generator=g); Xi = torch.randn(n, 5, generator=g)
+
+    def run(trunk):
+        for p in chebs.parameters():
+            p.grad = None
+        xr = Xr.to(DEV).requires_grad_(True); xi = Xi.to(DEV).requires_grad_(True)
+        if trunk:
+            out = M._run_trunk(chebs, xr, xi)
+        else:
+            r, i = xr, xi
+            for m in chebs:
+                r, i = m((r, i)) if isinstance(m, M.ChebConv) else m(r, i)
+            out = torch.stack([r, i], dim=1)
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+        return [out.detach().cpu()] + [xr.grad.cpu(), xi.grad.cpu()] + [p.grad.cpu() for p in chebs.parameters()]
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert_close(x.numpy(), y.numpy(), rel=2e-6)
+    # oracle forward of the same stack
+    r, i = Xr, Xi
+    for m in chebs:
+        if isinstance(m, M.ChebConv):
+            r, i = O.cheb_conv_recursion(Ls, m.weight.detach().cpu(), m.bias.detach().cpu(), r, i)
+        else:
+            r, i = O.complex_relu(r, i)
+    assert_close(a[0][:, 0].numpy(), np.asarray(r), rel=2e-5)
+    assert_close(a[0][:, 1].numpy(), np.asarray(i), rel=2e-5)
