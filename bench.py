@@ -201,6 +201,11 @@ def epoch_time(rank, world, dev, multi):
 
 def main():
     args = parse_args()
+    # stdout carries the one JSON line and nothing else: libraries that print to file descriptor 1
+    # (RCCL writes a version banner there) are pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -343,9 +348,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(out))
+        result_line = json.dumps(out)
     if multi:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (result_line + '\n').encode())
+    os.close(json_fd)
 
 
 if __name__ == '__main__':
