@@ -224,6 +224,9 @@ class _ChebConvFn(torch.autograd.Function):
         k1, _, cout = weight.shape
         w = weight.detach()
         b = None if bias is None else bias.detach()
+        if in_block is not None and (tuple(in_block.shape) != (n, 2, k1, cin) or not in_block.is_contiguous()
+                                     or in_block.data_ptr() != xp.data_ptr()):
+            raise MagnetHipError('in_block must be the contiguous [N, 2, K+1, C_in] block whose order 0 is the input')
         gemm_first = cout < cin and in_block is None
         out = _alloc_out(n, cout, next_terms, xp.device)
         if gemm_first:
