@@ -329,7 +329,7 @@ def main():
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': 'power-law digraph N=%d E=%d (seed %d), %d complex features, K=%d, q=%g; step = one '
-                            'MagNetConv forward (K fused complex SpMM orders + K+1 weight GEMMs + bias)%s' % (
+                            'MagNetConv forward (K fused complex SpMM orders + one weight GEMM over the K+1 orders + bias)%s' % (
                                 n, e, args.seed, f, K, args.q, '; vertices randomly relabelled (seed 99)' if args.relabel else ''),
                 'nnz': nnz_total, 'parallelism': '%s%d' % (strategy, world) if multi else 'single',
             },
