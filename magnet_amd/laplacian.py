@@ -222,10 +222,12 @@ class MagneticLaplacian:
     # -- conversions ----------------------------------------------------------
     def to_scipy(self):
         import scipy.sparse as sp
-        val = self.val.cpu().numpy()
-        data = (val[:, 0] + 1j * val[:, 1]).astype(np.complex64) if self.nnz else np.zeros(0, np.complex64)
-        return sp.csr_matrix((data, self.col_idx.cpu().numpy(), self.row_ptr.cpu().numpy()),
-                             shape=(self.n_rows, self.n_cols))
+        # float32 (re, im) pairs ARE complex64 in memory: no host-side assembly
+        data = self.val.cpu().contiguous().numpy().view(np.complex64).reshape(-1) if self.nnz else np.zeros(0, np.complex64)
+        m = sp.csr_matrix((data, self.col_idx.cpu().numpy(), self.row_ptr.cpu().numpy()),
+                          shape=(self.n_rows, self.n_cols))
+        m.has_sorted_indices = True               # rows are emitted in column order
+        return m
 
     @staticmethod
     def from_scipy(mx, device='cuda'):
