@@ -349,12 +349,60 @@ class ColumnSharded:
         """All orders at once: list over orders of [rows_me, 2, F]."""
         return [self.finish_regroup(h) for h in [self.start_regroup(z) for z in zs]]
 
+    def _row_operator(self, p):
+        """The operator restricted to the output rows of rank p's block (built on first use)."""
+        ops = getattr(self, '_row_ops', None)
+        if ops is None:
+            ops = self._row_ops = {}
+        if p not in ops:
+            ops[p] = self.op.rows(self.rb[p], self.rb[p + 1])
+        return ops[p]
+
+    def last_order_staged(self, z_prev, z_prev2):
+        """The LAST order computed block by block — the rows each peer will own first, this rank's own
+        rows last — with every peer's block sent the moment it is done.  Nothing follows the last order
+        that its all-to-all could hide under, so it is hidden under the order's own remaining blocks.
+        Step s pairs rank r with r+s (send) and r-s (receive) on every rank at once, so each batch of
+        transfers is a permutation.  Returns a handle for finish_regroup."""
+        z = torch.empty_like(z_prev)
+        rows_me = self.r1 - self.r0
+        recv = [None] * self.world
+        works = []
+
+        def block(p):
+            a, b = self.rb[p], self.rb[p + 1]
+            if b > a:
+                if z_prev2 is None:
+                    self._row_operator(p).spmm(z_prev, out=z[a:b])
+                else:
+                    self._row_operator(p).spmm(z_prev, out=z[a:b], alpha=2.0, z1=z_prev2[a:b], beta1=-1.0)
+            return z[a:b]
+
+        for step in range(1, self.world):
+            to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
+            part = block(to)
+            recv[frm] = torch.empty((rows_me, 2, self.cb[frm + 1] - self.cb[frm]), dtype=z.dtype, device=z.device)
+            ops = []
+            if part.numel():
+                ops.append(dist.P2POp(dist.isend, part, to, self.group))
+            if recv[frm].numel():
+                ops.append(dist.P2POp(dist.irecv, recv[frm], frm, self.group))
+            if ops:
+                works += dist.batch_isend_irecv(ops)
+        recv[self.rank] = block(self.rank)
+        return works, recv, z
+
     def conv(self, x_slice, weight, bias):
         """Rows [r0, r1) of sum_k T_k X W_k + bias, given this rank's column slice of X.  The
-        regrouping of order k travels while order k+1 is being computed."""
+        regrouping of order k travels while order k+1 is being computed; the last order is computed in
+        row blocks whose transfers overlap the blocks still to come (last_order_staged)."""
         k1, cin, cout = weight.shape
         handles = []
-        self.cheb_terms(x_slice, k1, after_each=lambda k, z: handles.append(self.start_regroup(z)))
+        staged = self.world > 1 and k1 > 1 and hasattr(self.op, 'rows')
+        zs = self.cheb_terms(x_slice, k1 - 1 if staged else k1,
+                             after_each=lambda k, z: handles.append(self.start_regroup(z)))
+        if staged:
+            handles.append(self.last_order_staged(zs[-1], zs[-2] if k1 > 2 else None))
         rows_me = self.r1 - self.r0
         out = None
         for k, h in enumerate(handles):

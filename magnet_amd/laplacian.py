@@ -219,6 +219,12 @@ class MagneticLaplacian:
                                    stream_ptr(y.device)))
         return out, mask
 
+    def rows(self, r0, r1):
+        """The operator restricted to output rows [r0, r1) (column ids unchanged; col_idx / val are views)."""
+        a, b = int(self.row_ptr[r0]), int(self.row_ptr[r1])
+        rp = (self.row_ptr[r0:r1 + 1] - self.row_ptr[r0]).to(torch.int32)
+        return MagneticLaplacian(rp, self.col_idx[a:b], self.val[a:b], self.n_cols, q=self.q)
+
     # -- conversions ----------------------------------------------------------
     def to_scipy(self):
         import scipy.sparse as sp

@@ -24,6 +24,12 @@ class ScipyOperator:
         self.m = sp.csr_matrix((v[:, 0] + 1j * v[:, 1], ci.numpy(), rp.numpy()), shape=(rp.numel() - 1, n_cols))
         self.nnz = int(ci.numel())
 
+    def rows(self, r0, r1):
+        o = ScipyOperator.__new__(ScipyOperator)
+        o.m = self.m[r0:r1]
+        o.nnz = int(o.m.nnz)
+        return o
+
     def spmm(self, X, out=None, alpha=1.0, z1=None, beta1=0.0, z2=None, beta2=0.0, bias=None, relu=False, mask=None):
         c = lambda t: t[:, 0, :].detach().double().numpy() + 1j * t[:, 1, :].detach().double().numpy()
         y = alpha * (self.m @ c(X))
@@ -103,9 +109,8 @@ def _worker_cols(rank, world, port, n_terms, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_column_sharded_conv_matches_single_process(world, tmp_path):
-    n_terms = 4
+@pytest.mark.parametrize('world,n_terms', [(2, 4), (3, 4), (4, 3), (2, 2), (3, 1)])
+def test_column_sharded_conv_matches_single_process(world, n_terms, tmp_path):
     mp.spawn(_worker_cols, args=(world, _free_port(), n_terms, str(tmp_path)), nprocs=world, join=True)
     L, rp, ci, val = _graph()
     n, f, cout = L.shape[0], 10, 6

@@ -901,3 +901,23 @@ def test_trunk_hand_over_of_order_blocks():
             r, i = O.complex_relu(r, i)
     assert_close(a[0][:, 0].numpy(), np.asarray(r), rel=2e-5)
     assert_close(a[0][:, 1].numpy(), np.asarray(i), rel=2e-5)
+
+
+def test_row_block_operators_reproduce_the_whole_spmm():
+    """MagneticLaplacian.rows(a, b): the SpMM computed block by block (what the column-sharded multi-GPU
+    conv does for its last order, so that each peer's rows can leave as soon as they exist) is bitwise
+    the SpMM computed in one launch, hub rows included."""
+    mh, lap, H, M, O = _mods()
+    n, e = 60_000, 1_500_000
+    src, dst = lap.powerlaw_edges(n, e, 7, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    assert L.plan()[1] > 0                                   # the graph has hub rows handled by the plan
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n, 2, 32, device=DEV, generator=g); z1 = torch.randn(n, 2, 32, device=DEV, generator=g)
+    whole = L.spmm(x, alpha=2.0, z1=z1, beta1=-1.0)
+    parts = torch.empty_like(whole)
+    bounds = [0, 17, 20_000, 20_000, 45_001, n]               # uneven, one empty block
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b > a:
+            L.rows(a, b).spmm(x, out=parts[a:b], alpha=2.0, z1=z1[a:b], beta1=-1.0)
+    assert torch.equal(whole, parts)
