@@ -21,8 +21,11 @@ reference src/layer/sparse_magnet.py:8-165:
 
 Between layers features stay in the row-planar layout [N, 2, F] (one tensor holding the real
 and the imaginary block of every node); the (real, imag) tensors handed back are views of it.
-All sparse work, bias and the complex ReLU run in libmagnet_hip.so; the dense per-order weight
-GEMM is torch.mm (hipBLASLt).  GPU only.
+The K+1 propagated matrices of a conv sit side by side in one block [N, 2, K+1, F] (each order a strided
+view the SpMM works on in place), so the weights are applied by ONE GEMM per conv (torch.addmm, hipBLASLt)
+instead of the reference's K+1 matmul pairs; inside a network a conv writes its output directly into
+order 0 of the next conv's block.  All sparse work, bias and the complex ReLU run in libmagnet_hip.so.
+GPU only.
 """
 import math
 
