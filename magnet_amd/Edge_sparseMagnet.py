@@ -20,6 +20,7 @@ from . import data as D
 from .layer.sparse_magnet import ChebNet_Edge
 from .utils.edge_data import in_out_degree, generate_dataset_3class, link_prediction_evaluation, acc
 from .utils.preprocess import to_edge_dataset_sparse
+from .utils.save_settings import write_log
 
 
 def parse_args(argv=None):
@@ -123,6 +124,7 @@ def main(args):
                 torch.save(model.state_dict(), log_path + '/model' + str(i) + '.t7')
             else:
                 early_stopping += 1
+        write_log(vars(args), log_path)
 
         def outputs(path):
             model.load_state_dict(torch.load(path, weights_only=True))

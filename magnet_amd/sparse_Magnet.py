@@ -23,6 +23,7 @@ from . import data as D
 from .layer.sparse_magnet import ChebNet
 from .train import node_epoch, GraphedEpoch
 from .utils.preprocess import geometric_dataset_sparse
+from .utils.save_settings import write_log
 
 
 def parse_args(argv=None):
@@ -206,6 +207,7 @@ def main(args):
             if early_stopping > 500 or epoch == (args.epochs - 1):
                 torch.save(model.state_dict(), log_path + '/model_latest' + str(split) + '.t7')
                 break
+        write_log(vars(args), log_path)
 
         def evaluate(path):
             model.load_state_dict(torch.load(path, weights_only=True))

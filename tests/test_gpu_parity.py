@@ -3,6 +3,8 @@ golden vectors.  Needs an MI355X: every test is marked gpu.
 
 Bars: CSR structure (row_ptr / col_idx) bit-exact; values, forward and backward outputs within
 1e-5 relative in fp32 (conftest.assert_close)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -566,6 +568,17 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (1, 4) and res[0, 1] >= 0.9, res
     res = drv.run(['-D', '--dataset', 'syn/cyclic', '--q', '0.1', '--K', '1', '--splits', '1', '--log_root', str(tmp_path) + '/'])
     assert res.shape == (1, 4)
+    # the reference's smoke line `sparse_Magnet.py -D --dataset telegram/telegram` (execution/setup_test.sh:3)
+    import scipy.sparse as sp
+    row, col, n, w = _telegram(0.25, True)
+    os.makedirs(str(tmp_path / 'data' / 'telegram'), exist_ok=True)
+    sp.save_npz(str(tmp_path / 'data' / 'telegram' / 'telegram_adj.npz'), sp.coo_matrix((w, (row, col)), shape=(n, n)).tocsr())
+    np.save(str(tmp_path / 'data' / 'telegram' / 'telegram_labels.npy'), np.random.default_rng(0).integers(0, 4, n))
+    res = drv.run(['-D', '--dataset', 'telegram/telegram', '--q', '0.25', '--K', '1', '--splits', '2', '-a', '--num_filter', '8',
+                   '--data_path', str(tmp_path / 'data') + '/', '--log_root', str(tmp_path) + '/'])
+    assert res.shape == (2, 4) and np.isfinite(res).all()
+    import glob
+    assert glob.glob(str(tmp_path) + '/**/settings.csv', recursive=True)
     # --hip_graph replays the same epochs: the logged losses follow the eager run from epoch 0 on
     import glob, re
     logs = {}
