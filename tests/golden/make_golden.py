@@ -269,7 +269,61 @@ def telegram_cache():
     print('telegram_cache:', names)
 
 
+def config_cases(ref_h, ref_c, ChebNet):
+    """One training step (forward, NLL loss on a train mask, backward) of the reference's ChebNet at the
+    two small node-classification configurations the benchmark plan names:
+      cora  — the reference's dataset/cora/cora.edges + cora.node_labels (2 708 nodes, 5 429 edges,
+              1-based ids), X ~ N(0,1) [N, 64] (seed 0), q = 0.25, K = 1, 16 filters, 2 layers, ReLU;
+      dsbm  — cyclic DSBM, 5 clusters x 500 nodes (magnet_amd.data.dsbm_cyclic, seed 10: our own seeded
+              generator; the graph is an INPUT here), its N(0,1) [N, 1] features, q = 0.1, K = 2,
+              16 filters, 2 layers, ReLU.  The reference formulation precomputes the sparse T_2."""
+    out = {}
+    e = np.loadtxt(os.path.join(REF, 'dataset/cora/cora.edges'), delimiter=',', dtype=np.int64)
+    lab = np.loadtxt(os.path.join(REF, 'dataset/cora/cora.node_labels'), delimiter=',', dtype=np.int64)
+    n = int(max(e[:, :2].max(), lab[:, 0].max()))
+    y = np.zeros(n, np.int64); y[lab[:, 0] - 1] = lab[:, 1]
+    y = y - y.min()
+    graphs = {'cora': (e[:, 0] - 1, e[:, 1] - 1, n, y,
+                       torch.randn(n, 64, generator=torch.Generator().manual_seed(0)), 0.25, 1)}
+    sys.path.insert(0, os.path.join(HERE, '..', '..'))
+    from magnet_amd.data import dsbm_cyclic
+    d = dsbm_cyclic(p_q=0.95, seed=10)
+    graphs['dsbm'] = (d.edge_index[0].numpy(), d.edge_index[1].numpy(), int(d.x.size(0)), d.y.numpy(), d.x.clone(), 0.1, 2)
+    rng = np.random.default_rng(11)
+    for name, (row, col, n, y, X, q, K) in graphs.items():
+        L = ref_c(ref_h(row, col, n, q, norm=True, laplacian=True, max_eigen=2.0, gcn_appr=False), K)
+        Lr, Li = to_coo_lists(L)
+        torch.manual_seed(400 + K)
+        net = ChebNet(X.size(1), Lr, Li, num_filter=16, K=K, label_dim=int(y.max()) + 1, activation=True, layer=2, dropout=0.0)
+        for m in net.Chebs:
+            if hasattr(m, 'bias'):
+                with torch.no_grad():
+                    m.bias.uniform_(-0.3, 0.3)
+        Xr = X.clone().requires_grad_(True); Xi = X.clone().requires_grad_(True)
+        train = torch.from_numpy(rng.random(n) < 0.6)
+        preds = net(Xr, Xi)
+        loss = torch.nn.NLLLoss()(preds[:, :, train], torch.from_numpy(y[None])[:, train])
+        loss.backward()
+        out[name + '/row'] = row.astype(np.int32); out[name + '/col'] = col.astype(np.int32)
+        out[name + '/params'] = np.array([K, 2, 1.0, 16, q, X.size(1), n], np.float64)
+        out[name + '/X'] = X.numpy(); out[name + '/train'] = train.numpy(); out[name + '/y'] = y
+        out[name + '/preds'] = preds.detach().numpy(); out[name + '/loss'] = np.array(loss.item())
+        out[name + '/dXr'] = Xr.grad.numpy().copy(); out[name + '/dXi'] = Xi.grad.numpy().copy()
+        out[name + '/nnz'] = np.array([l.nnz for l in L])
+        for k, v in net.state_dict().items():
+            out[name + '/state/' + k] = v.numpy().copy()
+        for k, p in net.named_parameters():
+            out[name + '/grad/' + k] = p.grad.numpy().copy()
+        print('config case %s: n=%d E=%d nnz(T_k)=%s loss=%.6f' % (name, n, len(row), [l.nnz for l in L], loss.item()))
+    out['names'] = np.array(sorted(graphs))
+    np.savez_compressed(os.path.join(HERE, 'config_cases.npz'), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'configs':      # only the (slower) configuration cases
+        ref_h, ref_c, ChebConv, ChebNet, ChebNet_Edge = _import_reference()
+        config_cases(ref_h, ref_c, ChebNet)
+        sys.exit(0)
     telegram_cache()
     ref_h, ref_c, ChebConv, ChebNet, ChebNet_Edge = _import_reference()
     lap_cases(ref_h)
@@ -277,3 +331,4 @@ if __name__ == '__main__':
     conv_cases(ref_h, ref_c, ChebConv)
     net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge)
     citeseer_case(ref_h, ref_c, ChebNet_Edge)
+    config_cases(ref_h, ref_c, ChebNet)

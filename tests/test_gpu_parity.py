@@ -393,6 +393,47 @@ def test_networks_forward_backward(name, mode):
     assert_close(c(Xi.grad), NET[name + '/dXi'], what='dXi')
 
 
+CFG = load_golden('config_cases.npz')
+
+
+@pytest.mark.parametrize('mode', ['basis', 'reference_lists'])
+@pytest.mark.parametrize('name', [str(s) for s in CFG['names']])
+def test_benchmark_configurations_forward_backward(name, mode):
+    """BASELINE configurations 1 (Cora-sized citation graph, the reference's dataset/cora files, K=1,
+    q=0.25) and 2 (2 500-node cyclic DSBM, K=2, q=0.1): one training step of the reference's ChebNet
+    (predictions, loss, every parameter and input gradient) against the HIP path, with the feature-side
+    recursion and with the reference's precomputed T_k lists (T_2 of the DSBM has 6.2M nonzeros)."""
+    _, lap, H, M, O = _mods()
+    K, layer, act, F, q, cin, n = CFG[name + '/params']
+    K, layer, F, cin, n = int(K), int(layer), int(F), int(cin), int(n)
+    row, col = CFG[name + '/row'].astype(np.int64), CFG[name + '/col'].astype(np.int64)
+    if mode == 'basis':
+        Lr, Li = H.cheb_poly_sparse(H.hermitian_decomp_sparse_device(row, col, n, float(q)), K), None
+    else:
+        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(O.hermitian_decomp_sparse(row, col, n, float(q)), K))
+        Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
+    pre = name + '/state/'
+    state = {k[len(pre):]: torch.from_numpy(CFG[k].copy()) for k in CFG.files if k.startswith(pre)}
+    X = torch.from_numpy(CFG[name + '/X']).to(DEV)
+    Xr = X.clone().requires_grad_(True); Xi = X.clone().requires_grad_(True)
+    y = torch.from_numpy(CFG[name + '/y'])
+    net = M.ChebNet(cin, Lr, Li, num_filter=F, K=K, label_dim=int(y.max()) + 1, activation=bool(act), layer=layer,
+                    dropout=0.0).to(DEV)
+    net.load_state_dict(state)
+    preds = net(Xr, Xi)
+    train = torch.from_numpy(CFG[name + '/train']).to(DEV)
+    loss = torch.nn.NLLLoss()(preds[:, :, train], y[None].to(DEV)[:, train])
+    loss.backward()
+    c = lambda x: x.detach().cpu().numpy()
+    tol = 2e-5 if mode == 'basis' else 1e-5       # recursion vs precomputed T_2: two roundings apart
+    assert_close(c(preds), CFG[name + '/preds'], rel=tol, what='preds')
+    assert abs(loss.item() - float(CFG[name + '/loss'])) <= 1e-5 * abs(float(CFG[name + '/loss'])) + 1e-6
+    for k, p in net.named_parameters():
+        assert_close(c(p.grad), CFG[name + '/grad/' + k], rel=tol, what='grad ' + k)
+    assert_close(c(Xr.grad), CFG[name + '/dXr'], rel=tol, what='dXr')
+    assert_close(c(Xi.grad), CFG[name + '/dXi'], rel=tol, what='dXi')
+
+
 def test_citeseer_link_prediction_step():
     """Config-3 shaped step: CiteSeer graph, K=2, q=0.1, 16 filters, degree features, fwd + bwd."""
     _, lap, H, M, O = _mods()

@@ -115,6 +115,37 @@ def test_nets_match_reference(name):
         assert_close(out, NET[name + '/out'], what='out')
 
 
+CFG = load_golden('config_cases.npz')
+
+
+@pytest.mark.parametrize('name', [str(s) for s in CFG['names']])
+def test_benchmark_configurations_match_reference(name):
+    """The reference's ChebNet at the two small node-classification configurations (Cora citation
+    graph shipped with the reference; 2 500-node cyclic DSBM with its precomputed sparse T_2):
+    predictions of the reference against the oracle in both formulations."""
+    K, layer, act, F, q, cin, n = CFG[name + '/params']
+    K, layer, n = int(K), int(layer), int(n)
+    L = O.hermitian_decomp_sparse(CFG[name + '/row'].astype(np.int64), CFG[name + '/col'].astype(np.int64), n, float(q))
+    Ts = O.cheb_poly_sparse(L, K)
+    assert [t.nnz for t in Ts] == CFG[name + '/nnz'].tolist()
+    Lr, Li = O.laplacian_lists(Ts)
+    pre = name + '/state/'
+    state = {k[len(pre):]: torch.from_numpy(CFG[k].copy()) for k in CFG.files if k.startswith(pre)}
+    X = torch.from_numpy(CFG[name + '/X'])
+    out = O.chebnet_forward(state, Lr, Li, X, X, layer, bool(act))
+    assert_close(out, CFG[name + '/preds'], what='preds')
+    # feature-side recursion (what the HIP layers run) against the reference's precomputed-T_k numbers
+    r, i = X, X
+    for j in range(layer):
+        w, b = state['Chebs.%d.weight' % (2 * j)], state['Chebs.%d.bias' % (2 * j)]
+        r, i = O.cheb_conv_recursion(L, w, b, r, i)
+        r, i = O.complex_relu(r, i)
+    x = torch.cat((r, i), dim=-1)
+    logits = x @ state['Conv.weight'].squeeze(-1).t() + state['Conv.bias']
+    preds = torch.log_softmax(logits.t().unsqueeze(0), dim=1)
+    assert_close(preds, CFG[name + '/preds'], rel=2e-5, what='preds by recursion')
+
+
 def test_in_out_degree_quirk():
     g = load_golden('citeseer_link_case.npz')
     got = O.in_out_degree(torch.from_numpy(g['iod_small_in']), 5)
