@@ -716,11 +716,12 @@ class MagNetConv(nn.Module):
 
     def laplacian(self, edge_index, edge_weight, n):
         c = self._cache
-        if c is not None and c[0] is edge_index and c[1] is edge_weight and c[2] == n:
+        ver = (edge_index._version, None if edge_weight is None else edge_weight._version)
+        if c is not None and c[0] is edge_index and c[1] is edge_weight and c[2] == n and c[4] == ver:
             return c[3]
         lap = build_magnetic_laplacian(edge_index[0], edge_index[1], n, q=self.q, edge_weight=edge_weight,
                                        device=edge_index.device if edge_index.is_cuda else None)
-        self._cache = (edge_index, edge_weight, n, lap)
+        self._cache = (edge_index, edge_weight, n, lap, ver)      # same tensors, unmodified -> same graph
         return lap
 
     def forward(self, real, imag, edge_index, edge_weight=None):

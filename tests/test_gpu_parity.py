@@ -468,7 +468,10 @@ def test_magnetconv_edge_index_signature():
     Lo = O.hermitian_decomp_sparse(row, col, n, 0.25)
     rr, ri = O.cheb_conv_recursion(Lo, conv.weight.detach().cpu(), conv.bias.detach().cpu(), Xr.cpu(), Xi.cpu())
     assert_close(real.detach().cpu().numpy(), rr.numpy()); assert_close(imag.detach().cpu().numpy(), ri.numpy())
-    assert conv.laplacian(ei, None, n) is conv.laplacian(ei, None, n)          # cached per graph tensor
+    first = conv.laplacian(ei, None, n)
+    assert conv.laplacian(ei, None, n) is first                               # cached per graph tensor
+    ei[:, 0] = ei[:, 0].flip(0)                                                # edited in place: rebuilt
+    assert conv.laplacian(ei, None, n) is not first
 
 
 def test_row_partition_operators_on_gpu():
