@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_counts(const int32_t* 
 
 // ---------------------------------------------------------------------------
 // 3b. (row, col) segments.  The thread on a segment's first record walks the segment:
-// forward records come first (dir is the key's lowest bit), each side is summed in fp32 in
+// forward records come first (they precede the backward ones in the input and the sort is stable;
+// dir is the key's lowest bit), each side is summed in fp32 in
 // stored (= input) order.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
@@ -363,8 +364,11 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
 
     MH_HIP(hipMemsetAsync(hdr, 0, 256, stream));
     MH_HIP(hipMemsetAsync(flags, 0, size_t(L.m_pad), stream));
-    // an odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1
-    const bool start_in_0 = mhsort::passes_for(2 * L.cb + 1) & 1;
+    // The sort key is (row, col) = key bits [1, 2cb+1).  The direction bit 0 is NOT sorted: all forward
+    // records are written before all backward records and the sort is stable, so inside a (row, col)
+    // segment the forward records still come first, each side in input order.
+    // An odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1.
+    const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
     uint64_t* rec_keys = start_in_0 ? keys0 : keys1;
     float* rec_w = weighted ? (start_in_0 ? w0 : w1) : nullptr;
     if (L.e_total > 0) {
@@ -380,7 +384,7 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
         // passes alternate between the two buffers; the records were written so that the result lands in keys1
         uint64_t* other = rec_keys == keys0 ? keys1 : keys0;
         float* other_w = weighted ? (rec_w == w0 ? w1 : w0) : nullptr;
-        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 2 * L.cb + 1, ws + L.off_sort, L.sort_bytes, stream));
+        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, ws + L.off_sort, L.sort_bytes, stream));
     }
     row_starts<<<grid_for(L.m + 1), kBlock, 0, stream>>>(keys1, L.m, n_nodes, L.cb, rec_ptr);
     MH_LAUNCH_CHECK("row_starts");

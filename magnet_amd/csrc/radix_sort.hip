@@ -189,8 +189,8 @@ size_t workspace_bytes(int64_t n) {
     return align_up(size_t(tiles) * kBins * 4) + align_up(size_t(chunks) * kBins * 4);
 }
 
-hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int bits, void* workspace, size_t ws_bytes,
-                hipStream_t stream) {
+hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int first_bit, int bits, void* workspace,
+                size_t ws_bytes, hipStream_t stream) {
     if (n <= 0 || bits <= 0) return hipSuccess;
     if (ws_bytes < workspace_bytes(n) || n >= (int64_t(1) << 32)) return hipErrorInvalidValue;
     const int64_t tiles = (n + kTile - 1) / kTile;
@@ -198,11 +198,12 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int b
     uint32_t* hist = static_cast<uint32_t*>(workspace);
     uint32_t* chunk = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align_up(size_t(tiles) * kBins * 4));
     const bool pairs = va != nullptr;
-    // equal digit widths over the passes (49 key bits -> 7 passes of 7 bits): fewer bins per pass
+    // equal digit widths over the passes (42 key bits -> 6 passes of 7 bits): fewer bins per pass
     // means longer runs of equal digit per tile, i.e. longer contiguous writes
     const int width = (bits + passes_for(bits) - 1) / passes_for(bits);
-    for (int shift = 0; shift < bits; shift += width) {
-        const int nb = bits - shift < width ? bits - shift : width;
+    for (int done = 0; done < bits; done += width) {
+        const int shift = first_bit + done;
+        const int nb = bits - done < width ? bits - done : width;
         const uint32_t mask = (1u << nb) - 1u;
         tile_histogram<<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist);
         scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
