@@ -978,3 +978,35 @@ def test_row_block_operators_reproduce_the_whole_spmm():
         if b > a:
             L.rows(a, b).spmm(x, out=parts[a:b], alpha=2.0, z1=z1[a:b], beta1=-1.0)
     assert torch.equal(whole, parts)
+
+
+def test_conv_block_path_at_full_size():
+    """Config-4 size (2M nodes / 40M edges, 128 features, K = 2): the conv over the side-by-side block
+    (strided SpMM operands, one GEMM over 3 x 128 columns, 1.5G-element block: 64-bit offsets) equals the
+    same conv assembled from separate contiguous SpMM calls and one GEMM per order."""
+    _, lap, H, M, O = _mods()
+    n, e, f, K = 2_000_000, 40_000_000, 128, 2
+    src, dst = lap.powerlaw_edges(n, e, 42, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    del src, dst
+    torch.manual_seed(21)
+    conv = M.ChebConv(f, f, K, H.cheb_poly_sparse(L, K), None).to(DEV)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.2, 0.2)
+    block = torch.empty(n, 2, K + 1, f, device=DEV)
+    xp = block[:, :, 0, :]
+    xp.normal_(generator=torch.Generator(device=DEV).manual_seed(22))
+    x = xp.contiguous()
+    with torch.no_grad():
+        got = conv.forward_packed(xp, relu=False, in_block=block)
+        z1 = L.spmm(x)
+        z2 = L.spmm(z1, alpha=2.0, z1=x, beta1=-1.0)
+        ref = torch.addmm(conv.bias, x.view(2 * n, f), conv.weight[0])
+        ref.addmm_(z1.view(2 * n, f), conv.weight[1]); ref.addmm_(z2.view(2 * n, f), conv.weight[2])
+        ref = ref.view(n, 2, f)
+        assert torch.equal(block[:, :, 1, :], z1) and torch.equal(block[:, :, 2, :], z2)     # same kernel, same order
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-5 * scale
+        # the fused complex ReLU gates both parts on the sign of the conv's own real part
+        gated = conv.forward_packed(xp, relu=True, in_block=block)
+        assert torch.equal(gated, got * (got[:, 0, :] >= 0).unsqueeze(1))
