@@ -311,16 +311,7 @@ def main():
 
     ceiling = stream_ceilings(dev) if rank == 0 else None
 
-    epoch = None
-    if not args.no_epoch:
-        del step, launches
-        layer = conv = xp = block = lap = None
-        torch.cuda.empty_cache()
-        try:
-            epoch = epoch_time(rank, world, dev, multi)
-        except Exception as ex:                         # the headline metric must still be reported
-            epoch = {'error': repr(ex)[:300]}
-
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -344,16 +335,47 @@ def main():
             'spmm_edges_per_s': nnz_total * K * args.steps / (k_ms * 1e-3) if k_ms > 0 and world == 1 else None,
             'input_edges_per_s': e * K / (elapsed / args.steps),
             'builder_edges_per_s': e / t_build, 'builder_ms': t_build * 1e3,
-            'epoch': epoch,
+            'epoch': None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+
+    def emit():
+        sys.stdout.flush()
+        if rank == 0:
+            os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+    # The headline above is complete.  The secondary measurements that follow must not be able to lose it:
+    # if they have not finished after 6 minutes (a collective that never completes), rank 0 prints the
+    # line without them and the process ends.
+    def give_up():
+        if out is not None:
+            out['epoch'] = {'error': 'secondary epoch measurement did not finish within 360 s'}
+        emit()
+        os._exit(0)
+
+    import threading
+    watchdog = threading.Timer(360.0, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
+    if not args.no_epoch:
+        del step, launches
+        layer = conv = xp = block = lap = None
+        torch.cuda.empty_cache()
+        try:
+            epoch = epoch_time(rank, world, dev, multi)
+        except Exception as ex:                         # the headline metric must still be reported
+            epoch = {'error': repr(ex)[:300]}
+        if out is not None:
+            out['epoch'] = epoch
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
             out['cpu_baseline'] = cpu_baseline(args)
-        result_line = json.dumps(out)
+        except Exception as ex:
+            out['cpu_baseline'] = {'error': repr(ex)[:300]}
     if multi:
         dist.destroy_process_group()
-    sys.stdout.flush()
-    if rank == 0:
-        os.write(json_fd, (result_line + '\n').encode())
+    watchdog.cancel()
+    emit()
     os.close(json_fd)
 
 
