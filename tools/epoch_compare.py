@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Epoch time of the small reference configurations on one MI355X: this package (eager and as a
 HIP graph) next to the reference formulation (uncoalesced torch.sparse COO, 4 spmm + 4 matmul per
-order with precomputed sparse T_k) run on the same GPU through the oracle's restatement."""
+order with precomputed sparse T_k) run on the same GPU, restated below with torch's own sparse kernels."""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ from magnet_amd import data as D                                               #
 from magnet_amd.layer.sparse_magnet import ChebNet                              # noqa: E402
 from magnet_amd.utils.hermitian import hermitian_decomp_sparse_device, cheb_poly_sparse   # noqa: E402
 from magnet_amd.train import node_epoch, GraphedEpoch                           # noqa: E402
-from oracle import magnet_oracle as O                                           # noqa: E402
+from magnet_amd.sparse_Magnet import sparse_mx_to_torch_sparse_tensor          # noqa: E402
 
 dev = 'cuda'
 
@@ -31,6 +31,24 @@ def timeit(fn, iters):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def reference_formulation(state, Lr, Li, X, layer):
+    """ChebNet forward as the reference computes it (src/layer/sparse_magnet.py:8-18,60-72,79-81,
+    119-130): per order four torch.spmm on the precomputed T_k and two matmuls, bias on both parts,
+    complex ReLU, 1x1 Conv1d head."""
+    real = imag = X
+    for j in range(layer):
+        w, b = state['Chebs.%d.weight' % (2 * j)], state['Chebs.%d.bias' % (2 * j)]
+        r = i = 0.0
+        for k in range(len(Lr)):
+            r = r + torch.matmul(torch.spmm(Lr[k], real) - torch.spmm(Li[k], imag), w[k])
+            i = i + torch.matmul(torch.spmm(Li[k], real) + torch.spmm(Lr[k], imag), w[k])
+        mask = 1.0 * (r + b >= 0)
+        real, imag = mask * (r + b), mask * (i + b)
+    x = torch.cat((real, imag), dim=-1).unsqueeze(0).permute(0, 2, 1)
+    x = torch.nn.functional.conv1d(x, state['Conv.weight'], state['Conv.bias'])
+    return torch.log_softmax(x, dim=1)
+
+
 def run(name, g, q, K, Fh, layer, iters=200):
     n = g.x.size(0)
     ncls = int(g.y.max()) + 1
@@ -43,18 +61,18 @@ def run(name, g, q, K, Fh, layer, iters=200):
     graphed = GraphedEpoch(lambda: node_epoch(net, opt, X, X, y, tr, va))
     gms = timeit(graphed, iters)
     # reference formulation on the same GPU
-    Lo = L.to_scipy()
-    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, K))
-    Lr = [t.to(dev) for t in Lr]; Li = [t.to(dev) for t in Li]
+    Ts = list(cheb_poly_sparse(L, K))                     # the sparse T_k the reference precomputes (host SpGEMM)
+    Lr = [sparse_mx_to_torch_sparse_tensor(t.real).to(dev) for t in Ts]
+    Li = [sparse_mx_to_torch_sparse_tensor(t.imag).to(dev) for t in Ts]
     state = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     opt2 = torch.optim.Adam(list(state.values()), lr=5e-3, weight_decay=5e-4)
 
     def ref_epoch():
-        preds = O.chebnet_forward(state, Lr, Li, X, X, layer, True)
+        preds = reference_formulation(state, Lr, Li, X, layer)
         loss = torch.nn.NLLLoss()(preds[:, :, tr], y[:, tr])
         opt2.zero_grad(); loss.backward(); opt2.step()
         with torch.no_grad():
-            O.chebnet_forward(state, Lr, Li, X, X, layer, True)
+            reference_formulation(state, Lr, Li, X, layer)
     ref = timeit(ref_epoch, max(iters // 4, 10))
     print(json.dumps(dict(config=name, nodes=n, edges=int(g.edge_index.size(1)), nnz=L.nnz, K=K, filters=Fh,
                           epoch_ms_eager=round(eager, 3), epoch_ms_hipgraph=round(gms, 3),
