@@ -73,9 +73,15 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ['mh_version', 'mh_last_error', 'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
-           'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill', 'mh_cheb_terms', 'mh_clenshaw', 'mh_unpack', 'mh_gather_rows',
-           'mh_scatter_rows', 'mh_pack', 'mh_bias_relu', 'mh_relu_bwd', 'mh_powerlaw_edges', 'mh_stream_read']
+# every symbol include/magnet_hip.h declares (tests/test_abi_cpu.py compares the two lists)
+EXPORTS = [
+    'mh_version', 'mh_last_error',
+    'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
+    'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
+    'mh_cheb_terms', 'mh_clenshaw',
+    'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd',
+    'mh_powerlaw_edges', 'mh_stream_read',
+]
 
 
 def check(rc):

@@ -63,6 +63,9 @@ def _as_packed(real, imag):
 
 
 def _views(p):
+    """(real, imag) views of a row-planar tensor.  Each view remembers the tensor it was cut from, so a
+    layer that is handed the pair back (the reference passes (real, imag) tuples between layers) finds the
+    packed tensor again instead of packing a copy (_as_packed)."""
     real, imag = p[:, 0, :], p[:, 1, :]
     real._mh_packed = p
     imag._mh_packed = p
