@@ -481,9 +481,16 @@ class ShardedChebNet:
     The classification head is row-local.  Parameter gradients are summed over ranks (all-reduce);
     the loss is the global mean over the training nodes."""
 
+    # As on one GPU (ChebConv.cache_input_propagation), the propagated input T_k(L) X of the FIRST layer does
+    # not depend on any weight.  With this switch on it is computed once on the column slices, regrouped to
+    # this rank's row block and kept for as long as the same, unmodified input tensor is passed: the first
+    # layer then costs one row-local GEMM per forward, no SpMM and no communication.
+    cache_input_propagation = False
+
     def __init__(self, net, operator, n, rank, world, group=None):
         from .layer.sparse_magnet import ChebConv, complex_relu_layer
         self.net, self.op, self.n, self.rank, self.world, self.group = net, operator, n, rank, world, group
+        self._input_cache = None
         self.rb = [n * p // world for p in range(world)] + [n]
         self.r0, self.r1 = self.rb[rank], self.rb[rank + 1]
         mods = list(net.Chebs)
@@ -503,7 +510,26 @@ class ShardedChebNet:
         from .layer.sparse_magnet import _ChebTermsFn, _ClenshawFn, _ComplexReluFn
         x, layout = x_rows, 'rows'
         rows_me = self.r1 - self.r0
-        for conv, relu in self.layers:
+        layers = self.layers
+        conv0, relu0 = layers[0]
+        if (self.cache_input_propagation and not x_rows.requires_grad and conv0.weight.size(1) >= self.world):
+            from .layer.sparse_magnet import _cheb_terms
+            w, b = conv0.weight, conv0.bias
+            k1, cin, cout = w.shape
+            c = self._input_cache
+            if c is None or c[0] is not x_rows or c[1] != x_rows._version or c[3] != k1:
+                with torch.no_grad():
+                    cb = column_bounds(cin, self.world)
+                    xc = _regroup(x_rows.unsqueeze(2), self.rb, cb, self.rank, self.world, self.group, True).squeeze(2)
+                    z = _cheb_terms(self.op, xc, k1)                                   # [N, 2, k1, my columns]
+                    r = _regroup(z, self.rb, cb, self.rank, self.world, self.group, False)   # [rows_me, 2, k1, C_in]
+                c = self._input_cache = (x_rows, x_rows._version, r, k1)
+            out = torch.matmul(c[2].reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
+            if b is not None:
+                out = out + b.reshape(1, 1, cout)
+            x = _ComplexReluFn.apply(out) if relu0 else out
+            layers = layers[1:]
+        for conv, relu in layers:
             w, b = conv.weight, conv.bias
             k1, cin, cout = w.shape
             if layout == 'rows':

@@ -761,6 +761,17 @@ def test_sharded_chebnet_single_rank_matches_chebnet_on_gpu():
         torch.nn.NLLLoss()(out, y).backward()
         for k, p in net.named_parameters():
             assert_close(p.grad.cpu().numpy(), gref[k].cpu().numpy(), rel=2e-5, what='grad ' + k)
+        # first layer served from the kept T_k(L) X: same numbers, cache filled once per input tensor
+        net.zero_grad()
+        sh.cache_input_propagation = True
+        xp = torch.stack([X, X], dim=1)
+        out1 = sh.forward(xp); kept = sh._input_cache[2]
+        out2 = sh.forward(xp)
+        assert sh._input_cache[2] is kept and torch.equal(out1, out2)
+        assert_close(out2.detach().cpu().numpy(), ref.detach().cpu().numpy(), rel=2e-5, what='sharded forward, cached input')
+        torch.nn.NLLLoss()(out2, y).backward()
+        for k, p in net.named_parameters():
+            assert_close(p.grad.cpu().numpy(), gref[k].cpu().numpy(), rel=2e-5, what='cached grad ' + k)
 
 
 def test_recursion_entry_points_and_row_staging(small_graph):
