@@ -70,6 +70,8 @@ def load_graph(args):
         return D.load_npz_citation(os.path.join(args.data_path, name, name + '.npz'))
     if head == 'telegram':
         return D.load_telegram(os.path.join(args.data_path, 'telegram'))
+    if head in ('WebKB', 'WikipediaNetwork'):
+        return D.load_geom_gcn_raw(args.data_path + args.dataset, args.dataset.split('/')[1], args.data_path)
     raise ValueError('dataset %s needs torch_geometric downloads, which are not available here' % args.dataset)
 
 

@@ -149,6 +149,49 @@ def load_telegram(folder, n_splits=10):
                      train_mask=torch.from_numpy(tr), val_mask=torch.from_numpy(va), test_mask=torch.from_numpy(te))
 
 
+def load_geom_gcn_raw(root, name, data_path=None):
+    """WebKB / WikipediaNetwork graphs in the Geom-GCN raw layout that torch_geometric downloads and the
+    reference reads through it (src/sparse_Magnet.py:77-80; the reference tree ships texas and wisconsin):
+        <dir>/<name>/raw/out1_node_feature_label.txt   node_id <tab> f0,f1,... <tab> label   (header line)
+        <dir>/<name>/raw/out1_graph_edges.txt          src <tab> dst                         (header line)
+        <dir>/<name>/raw/<name>_split_0.6_0.2_<i>.npz  train_mask / val_mask / test_mask, i = 0..9
+    with <name> lower-cased and <dir> = root or data_path.  Edges stay directed; duplicates are dropped
+    (torch_geometric coalesces them)."""
+    low = name.lower()
+    raw = None
+    for base in (root, data_path):
+        if base and os.path.isfile(os.path.join(base, low, 'raw', 'out1_graph_edges.txt')):
+            raw = os.path.join(base, low, 'raw')
+            break
+    if raw is None:
+        raise FileNotFoundError('no Geom-GCN raw files for %s under %s or %s (torch_geometric would download them; '
+                                'there is no network here)' % (name, root, data_path))
+    feats, labels = {}, {}
+    with open(os.path.join(raw, 'out1_node_feature_label.txt')) as f:
+        next(f)
+        for line in f:
+            parts = line.rstrip('\n').split('\t')
+            if len(parts) < 3:
+                continue
+            i = int(parts[0])
+            feats[i] = np.array(parts[1].split(','), dtype=np.float32)
+            labels[i] = int(parts[2])
+    n = max(feats) + 1
+    x = np.stack([feats[i] for i in range(n)])
+    y = np.array([labels[i] for i in range(n)], dtype=np.int64)
+    e = np.loadtxt(os.path.join(raw, 'out1_graph_edges.txt'), dtype=np.int64, skiprows=1, ndmin=2)
+    e = np.unique(e, axis=0)                                   # (src, dst) sorted, duplicates removed
+    masks = {'train_mask': [], 'val_mask': [], 'test_mask': []}
+    for i in range(10):
+        z = np.load(os.path.join(raw, '%s_split_0.6_0.2_%d.npz' % (low, i)), allow_pickle=False)
+        for k in masks:
+            masks[k].append(z[k].astype(bool))
+    tr, va, te = (np.stack(masks[k], axis=1) for k in ('train_mask', 'val_mask', 'test_mask'))
+    return GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(e.T.copy()), edge_weight=None,
+                     y=torch.from_numpy(y), train_mask=torch.from_numpy(tr), val_mask=torch.from_numpy(va),
+                     test_mask=torch.from_numpy(te))
+
+
 def load_edge_csv(edges_path, labels_path=None):
     """`i,j,w` edge list with 1-based ids (dataset/cora/cora.edges) and optional `i,label` file."""
     e = np.loadtxt(edges_path, delimiter=',', dtype=np.int64)

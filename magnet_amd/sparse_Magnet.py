@@ -6,8 +6,9 @@
 Same flags, same loop (full-batch Adam, NLL loss on the training mask, validation forward, best /
 latest checkpoints as model{split}.t7 / model_latest{split}.t7, early stopping after 500 epochs
 without improvement, log{split}.csv, results array), on the HIP path.  Datasets that need
-torch_geometric downloads are not available offline; `syn/cyclic` is generated (magnet_amd.data),
-`telegram/telegram`, `citeseer_npz/`, `cora_ml/` are read from --data_path when present.
+torch_geometric downloads are not available offline; `syn/...` graphs are generated (magnet_amd.data),
+`telegram/telegram`, `citeseer_npz/`, `cora_ml/` and the WebKB / WikipediaNetwork graphs (Geom-GCN raw files,
+e.g. --dataset WebKB/Texas) are read from --data_path when present.
 """
 import argparse
 import os
@@ -144,6 +145,8 @@ def make_loader(args):
         return lambda root, name=None: [D.load_telegram(os.path.dirname(os.path.normpath(root)))]
     if head in ('cora_ml', 'citeseer_npz'):
         return lambda root, name=None: [D.load_npz_citation(root)]
+    if head in ('WebKB', 'WikipediaNetwork'):
+        return lambda root, name=None: [D.load_geom_gcn_raw(root, name, args.data_path)]
     raise ValueError('dataset %s needs torch_geometric downloads, which are not available here' % args.dataset)
 
 

@@ -623,6 +623,16 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (2, 4) and np.isfinite(res).all()
     import glob
     assert glob.glob(str(tmp_path) + '/**/settings.csv', recursive=True)
+    # WebKB graphs in the Geom-GCN raw layout (reference: --dataset WebKB/Texas through torch_geometric)
+    from test_host_logic import _write_geom_gcn_raw
+    _write_geom_gcn_raw(str(tmp_path / 'data'), 'Texas')
+    res = drv.run(['-D', '--dataset', 'WebKB/Texas', '--q', '0.25', '--K', '2', '--splits', '3', '-a', '--num_filter', '8',
+                   '--data_path', str(tmp_path / 'data') + '/', '--log_root', str(tmp_path) + '/'])
+    assert res.shape == (3, 4) and np.isfinite(res).all()
+    from magnet_amd import Edge_sparseMagnet as edrv
+    res = edrv.run(['-D', '--dataset', 'WebKB/Texas', '--task', '2', '--num_class_link', '3', '--q', '0.1', '--K', '1', '-a',
+                    '--num_filter', '8', '--splits', '1', '--data_path', str(tmp_path / 'data') + '/', '--log_root', str(tmp_path) + '/'])
+    assert res.shape[0] == 1 and np.isfinite(res).all()
     # --hip_graph replays the same epochs: the logged losses follow the eager run from epoch 0 on
     import glob, re
     logs = {}

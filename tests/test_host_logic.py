@@ -1,5 +1,6 @@
 """Host-side pieces that need no GPU: degree features, link metrics, the safe cache reader."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -153,3 +154,44 @@ def test_driver_dataset_names_and_saved_settings(tmp_path):
         drv.rename_syn_dataset(a5)
         assert drv.apply_saved_settings(a5) is True
         assert (a5.K, a5.layer, a5.num_filter, a5.lr, a5.q) == (1, 3, 16, 0.01, 0.05)
+
+
+def _write_geom_gcn_raw(folder, name, n=40, f=7, e=150, seed=0):
+    import os
+    rng = np.random.default_rng(seed)
+    raw = os.path.join(folder, name.lower(), 'raw')
+    os.makedirs(raw, exist_ok=True)
+    x = (rng.random((n, f)) < 0.3).astype(int); y = rng.integers(0, 3, n)
+    with open(os.path.join(raw, 'out1_node_feature_label.txt'), 'w') as fh:
+        fh.write('node_id\tfeature\tlabel\n')
+        for i in rng.permutation(n):                       # rows need not be in id order
+            fh.write('%d\t%s\t%d\n' % (i, ','.join(map(str, x[i])), y[i]))
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    with open(os.path.join(raw, 'out1_graph_edges.txt'), 'w') as fh:
+        fh.write('node_id\tnode_id\n')
+        for a, b in zip(src, dst):
+            fh.write('%d\t%d\n' % (a, b))
+    for i in range(10):
+        perm = np.random.default_rng(i).permutation(n)
+        m = np.zeros((3, n), np.uint8); m[0, perm[:24]] = 1; m[1, perm[24:32]] = 1; m[2, perm[32:]] = 1
+        np.savez(os.path.join(raw, '%s_split_0.6_0.2_%d.npz' % (name.lower(), i)), train_mask=m[0], val_mask=m[1], test_mask=m[2])
+    return x, y, np.unique(np.stack([src, dst], 1), axis=0)
+
+
+def test_geom_gcn_raw_loader(tmp_path):
+    """WebKB-style raw files (the layout torch_geometric downloads, read by the reference through
+    WebKB(root, name)): features, labels, directed de-duplicated edges, the ten 60/20/20 splits."""
+    import os
+    from magnet_amd import data as D
+    x, y, edges = _write_geom_gcn_raw(str(tmp_path), 'Texas')
+    g = D.load_geom_gcn_raw(str(tmp_path / 'WebKB' / 'Texas'), 'Texas', str(tmp_path))
+    assert np.array_equal(g.x.numpy(), x.astype(np.float32)) and np.array_equal(g.y.numpy(), y)
+    assert np.array_equal(g.edge_index.numpy().T, edges)
+    assert g.train_mask.shape == (40, 10) and g.train_mask.dtype == torch.bool
+    assert int(g.train_mask[:, 3].sum()) == 24 and not bool((g.train_mask & g.val_mask).any())
+    with pytest.raises(FileNotFoundError):
+        D.load_geom_gcn_raw(str(tmp_path), 'Cornell')
+    ref = '/root/reference/dataset/data/tmp/'
+    if os.path.isdir(ref + 'texas/raw'):                  # the copy the reference ships (build container only)
+        t = D.load_geom_gcn_raw(ref + 'WebKB/Texas', 'Texas', ref)
+        assert tuple(t.x.shape) == (183, 1703) and t.edge_index.size(1) == 325 and int(t.train_mask[:, 0].sum()) == 87
