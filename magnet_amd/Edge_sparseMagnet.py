@@ -63,6 +63,8 @@ def sparse_mx_to_torch_sparse_tensor(sparse_mx):
 
 def load_graph(args):
     head = args.dataset.split('/')[0]
+    if os.path.isfile(args.data_path + args.dataset + '.pk'):
+        return D.load_syn(args.data_path + args.dataset)[0]      # the reference's stored dataset, read inertly
     if head == 'syn':
         return D.dsbm_cyclic(p_q=args.p_q, seed=args.seed)
     if head in ('cora_ml', 'citeseer'):

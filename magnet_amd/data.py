@@ -149,6 +149,20 @@ def load_telegram(folder, n_splits=10):
                      train_mask=torch.from_numpy(tr), val_mask=torch.from_numpy(va), test_mask=torch.from_numpy(te))
 
 
+def load_syn(root, name=None):
+    """`root + '.pk'`: a dataset the reference stores as a pickled torch_geometric Data object — its
+    synthetic DSBM graphs `syn/*.pk` and `telegram/telegram.pk` (reference src/utils/preprocess.py:103-111).
+    The file is read by walking the pickle opcodes (utils.inert_pickle): nothing in it is executed."""
+    from .utils.inert_pickle import read_object_state
+    d = read_object_state(root + '.pk')
+    t = lambda v: v if v is None or torch.is_tensor(v) else torch.from_numpy(np.asarray(v))
+    ew = d.get('edge_weight')
+    g = GraphData(x=t(d['x']).float(), edge_index=t(d['edge_index']).long(), y=t(d['y']).long(),
+                  train_mask=t(d['train_mask']).bool(), val_mask=t(d['val_mask']).bool(), test_mask=t(d['test_mask']).bool())
+    g.edge_weight = None if ew is None else t(ew).float()
+    return [g]
+
+
 def load_geom_gcn_raw(root, name, data_path=None):
     """WebKB / WikipediaNetwork graphs in the Geom-GCN raw layout that torch_geometric downloads and the
     reference reads through it (src/sparse_Magnet.py:77-80; the reference tree ships texas and wisconsin):

@@ -11,7 +11,13 @@ nodes that describe ``numpy.ndarray`` reconstructions into arrays by
 
 Only the opcodes that numpy / scipy-sparse pickles of protocol <= 5 use are
 implemented; anything else raises.
+
+torch tensors inside such a pickle appear as `torch._utils._rebuild_tensor_v2(storage, offset, size,
+stride, ...)` with the storage given as `torch.storage._load_from_bytes(<bytes>)`: the bytes are a
+serialized storage, which is read with `torch.load(..., weights_only=True)` (torch's restricted
+loader) and viewed with the recorded offset / size / stride — again nothing named by the file runs.
 """
+import io
 import pickletools
 
 import numpy as np
@@ -137,6 +143,10 @@ def to_numpy(node):
         if node.kind == 'reduce' and node.head == ('numpy.core.multiarray', 'scalar'):
             dt, raw = node.args
             return np.frombuffer(raw, dtype=_dtype_of(dt))[0]
+        if node.kind == 'reduce' and node.head == ('torch._utils', '_rebuild_tensor_v2'):
+            return _torch_tensor(node)
+        if node.kind == 'reduce' and node.head == ('collections', 'OrderedDict') and not node.args:
+            return {}
         if node.kind == 'newobj':
             d = {k: to_numpy(v) for k, v in (node.state or {}).items()}
             d['__class__'] = '.'.join(node.head)
@@ -147,6 +157,26 @@ def to_numpy(node):
     if isinstance(node, (list, tuple)):
         return type(node)(to_numpy(v) for v in node)
     return node
+
+
+def _torch_tensor(node):
+    import torch
+    storage, offset, size, stride = node.args[0], node.args[1], node.args[2], node.args[3]
+    if not (isinstance(storage, Inert) and storage.kind == 'reduce' and storage.head == ('torch.storage', '_load_from_bytes')):
+        raise ValueError('tensor storage is not an embedded byte string: %r' % (storage,))
+    st = torch.load(io.BytesIO(storage.args[0]), weights_only=True)           # restricted loader
+    flat = torch.empty(0, dtype=st.dtype).set_(st.untyped_storage() if hasattr(st, 'untyped_storage') else st)
+    return torch.as_strided(flat, tuple(size), tuple(stride), int(offset)).clone()
+
+
+def read_object_state(path):
+    """A pickled attribute-bag object (torch_geometric Data as the reference stores its synthetic and
+    telegram datasets) -> dict of its attributes, tensors and arrays converted, nothing executed."""
+    with open(path, 'rb') as f:
+        tree = to_numpy(load_inert(f.read()))
+    if not isinstance(tree, dict):
+        raise ValueError('%s does not hold an object with a plain attribute dictionary' % path)
+    return tree
 
 
 def read_sparse_list(path):

@@ -623,6 +623,21 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (2, 4) and np.isfinite(res).all()
     import glob
     assert glob.glob(str(tmp_path) + '/**/settings.csv', recursive=True)
+    # a stored synthetic dataset (pickled Data object, as the reference keeps them) takes precedence over generation
+    import pickle
+    from test_host_logic import _Bag
+    gq = torch.Generator().manual_seed(3)
+    bag = _Bag()
+    bag.x = torch.randn(120, 1, generator=gq); bag.edge_index = torch.randint(0, 120, (2, 900), generator=gq)
+    bag.y = torch.randint(0, 3, (120,), generator=gq); bag.edge_weight = None
+    m = torch.rand(120, 10, generator=gq)
+    bag.train_mask, bag.val_mask, bag.test_mask = m < 0.5, (m >= 0.5) & (m < 0.75), m >= 0.75
+    os.makedirs(str(tmp_path / 'data' / 'syn'), exist_ok=True)
+    with open(tmp_path / 'data' / 'syn' / 'cyclic95Seed10.pk', 'wb') as f:
+        pickle.dump(bag, f)
+    res = drv.run(['-D', '--dataset', 'syn/cyclic', '--p_q', '0.95', '--seed', '10', '--q', '0.1', '--K', '1', '--splits', '2',
+                   '--data_path', str(tmp_path / 'data') + '/', '--log_root', str(tmp_path) + '/'])
+    assert res.shape == (2, 4) and np.isfinite(res).all()
     # WebKB graphs in the Geom-GCN raw layout (reference: --dataset WebKB/Texas through torch_geometric)
     from test_host_logic import _write_geom_gcn_raw
     _write_geom_gcn_raw(str(tmp_path / 'data'), 'Texas')

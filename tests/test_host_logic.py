@@ -195,3 +195,35 @@ def test_geom_gcn_raw_loader(tmp_path):
     if os.path.isdir(ref + 'texas/raw'):                  # the copy the reference ships (build container only)
         t = D.load_geom_gcn_raw(ref + 'WebKB/Texas', 'Texas', ref)
         assert tuple(t.x.shape) == (183, 1703) and t.edge_index.size(1) == 325 and int(t.train_mask[:, 0].sum()) == 87
+
+
+class _Bag:
+    """Stand-in for torch_geometric.data.Data when writing a test pickle (never imported by the reader)."""
+
+
+def test_load_syn_reads_data_pickles_without_unpickling(tmp_path):
+    """The reference stores its synthetic and telegram datasets as pickled Data objects
+    (src/utils/preprocess.py:103-111); load_syn walks the opcodes and rebuilds the tensors from the
+    embedded storages with torch's restricted loader."""
+    import os
+    import pickle
+    from magnet_amd import data as D
+    g = torch.Generator().manual_seed(0)
+    b = _Bag()
+    b.x = torch.randn(30, 1, generator=g)
+    b.edge_index = torch.randint(0, 30, (2, 200), generator=g)
+    b.edge_attr = None
+    b.y = torch.randint(0, 4, (30,), generator=g)
+    b.edge_weight = np.arange(200, dtype=np.float64)
+    base = torch.rand(30, 20, generator=g) < 0.5
+    b.train_mask, b.val_mask, b.test_mask = base[:, :10], base[:, 10:], ~base[:, :10]     # non-contiguous views
+    with open(tmp_path / 'toy.pk', 'wb') as f:
+        pickle.dump(b, f)
+    d = D.load_syn(str(tmp_path / 'toy'))[0]
+    assert torch.equal(d.x, b.x) and torch.equal(d.edge_index, b.edge_index) and torch.equal(d.y, b.y)
+    assert torch.equal(d.train_mask, b.train_mask) and torch.equal(d.val_mask, b.val_mask) and torch.equal(d.test_mask, b.test_mask)
+    assert d.edge_weight.dtype == torch.float32 and torch.equal(d.edge_weight, torch.arange(200.0))
+    ref = '/root/reference/dataset/data/tmp/syn/syn3Seed0'
+    if os.path.isfile(ref + '.pk'):                       # build container only
+        r = D.load_syn(ref)[0]
+        assert tuple(r.x.shape) == (2500, 1) and r.edge_index.size(1) == 186984 and int(r.train_mask[:, 0].sum()) == 50
