@@ -132,15 +132,20 @@ def undirected_label2directed_label(adj, edge_pairs, task):
 
 def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15, 0.05), task=2, label_dim=2):
     """{split: {'graph': LongTensor [2, E_obs], 'undirected': ndarray, 'train' | 'validate' | 'test':
-    {'pairs': int [M, 2], 'label': int32 [M]}}} — the layout of reference :221-239; cached under the
-    reference's file name (a cache written by this function is a pickle of this process's own data)."""
+    {'pairs': int [M, 2], 'label': int32 [M]}}} — the layout of reference :221-239, cached under the
+    reference's file name (:259-263).  An existing cache — written here or shipped with the reference,
+    e.g. dataset/data/tmp/citeseer/task1dim2prob15_5.pk — is read by walking its pickle opcodes
+    (utils.inert_pickle), never unpickled."""
     import pickle as pk
     import scipy.sparse as sp
     save_file = save_path + 'task' + str(task) + 'dim' + str(label_dim) + 'prob' + str(int(probs[0] * 100)) + '_' + \
         str(int(probs[1] * 100)) + '.pk'
-    if os.path.exists(save_file) and os.path.exists(save_file + '.magnet_amd'):
+    if os.path.exists(save_file):
+        from .inert_pickle import load_inert, to_numpy
         with open(save_file, 'rb') as f:
-            return pk.load(f)
+            cached = to_numpy(load_inert(f.read()))
+        if isinstance(cached, dict) and all(i in cached for i in range(splits)):
+            return cached
     ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
     A = sp.coo_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(size, size), dtype=np.float32).tocsr()
     S = (A + A.T).tocoo()
@@ -172,5 +177,4 @@ def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15,
     os.makedirs(os.path.dirname(save_file) or '.', exist_ok=True)
     with open(save_file, 'wb') as f:
         pk.dump(out, f, protocol=pk.HIGHEST_PROTOCOL)
-    open(save_file + '.magnet_amd', 'w').write('written by magnet_amd.utils.edge_data.generate_dataset_3class\n')
     return out

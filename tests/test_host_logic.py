@@ -87,7 +87,17 @@ def test_link_split_generation(tmp_path):
                 if l < 2:
                     assert (a, b) not in obs and (b, a) not in obs
     again = generate_dataset_3class(d.edge_index, n, str(tmp_path) + '/x', splits=2, probs=[0.15, 0.05], task=2, label_dim=3)
-    assert torch.equal(again[0]['graph'], ds[0]['graph'])                              # cached
+    assert torch.equal(again[0]['graph'], ds[0]['graph'])                              # cached (read back inertly)
+    for part in ('train', 'validate', 'test'):
+        assert np.array_equal(again[1][part]['pairs'], ds[1][part]['pairs']) and np.array_equal(again[1][part]['label'], ds[1][part]['label'])
+    # a split cache the reference ships is used as it is (build container only)
+    import os, shutil
+    ref = '/root/reference/dataset/data/tmp/citeseer/task1dim2prob15_5.pk'
+    if os.path.isfile(ref):
+        os.makedirs(str(tmp_path / 'cs'), exist_ok=True)
+        shutil.copy(ref, str(tmp_path / 'cs' / 'task1dim2prob15_5.pk'))
+        c = generate_dataset_3class(None, 0, str(tmp_path / 'cs') + '/', splits=10, task=1, label_dim=2)
+        assert tuple(c[0]['graph'].shape) == (2, 3763) and c[0]['train']['pairs'].shape == (7345, 2)
     # existence task: two balanced classes
     p, l = undirected_label2directed_label(A, ds[0]['test']['pairs'], task=1)
     assert set(np.unique(l)) <= {0, 1} and abs(int((l == 0).sum()) - int((l == 1).sum())) <= 1
