@@ -623,6 +623,12 @@ def test_node_driver_learns_the_cyclic_dsbm(tmp_path):
     assert res.shape == (2, 4) and np.isfinite(res).all()
     import glob
     assert glob.glob(str(tmp_path) + '/**/settings.csv', recursive=True)
+    # ordered DSBM, p_q = 0.9, with the reference's saved best setting for it (syn/syn4 in src/Magnet_complete.pk:
+    # q=0.2, K=1, 2 layers, 16 filters, lr 0.01; published test accuracy 0.99)
+    res = drv.run(['--dataset', 'syn/syn', '--p_q', '0.9', '--seed', '0', '--q', '0.2', '--K', '1', '-a', '--num_filter', '16',
+                   '--layer', '2', '--epochs', '300', '--lr', '0.01', '--splits', '1', '-NS', '--hip_graph',
+                   '--log_root', str(tmp_path) + '/', '--randomseed', '1'])
+    assert res[0, 1] >= 0.93, res
     # a stored synthetic dataset (pickled Data object, as the reference keeps them) takes precedence over generation
     import pickle
     from test_host_logic import _Bag
