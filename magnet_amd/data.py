@@ -20,25 +20,27 @@ class GraphData:
 
 
 def random_splits(labels, n_splits=10, train_per_class=20, val_size=500, seed=0):
-    """[N, n_splits] boolean train / val / test masks: `train_per_class` nodes of every class,
-    `val_size` of the remaining nodes, the rest for testing (the scheme of the reference's
-    citation / synthetic splits, src/utils/Citation.py:56 and src/utils/generate_cyclic.py:154;
-    the draws themselves are this module's own seeded ones)."""
-    labels = np.asarray(labels)
+    """[N, n_splits] boolean train / val / test masks, drawn exactly as the reference draws them
+    (src/utils/Citation.py:128-246, called at :56 and from src/utils/generate_cyclic.py:154): split s uses
+    numpy's legacy RandomState(seed + s); per class in ascending order `train_per_class` nodes are chosen
+    without replacement from the class's nodes in index order, then `val_size` nodes from the sorted rest,
+    and everything left is the test set.  (A class smaller than `train_per_class` contributes all its
+    nodes; the reference would raise there.)"""
+    labels = np.asarray(labels).astype(np.int64)
     n = len(labels)
     tr = np.zeros((n, n_splits), bool); va = np.zeros((n, n_splits), bool); te = np.zeros((n, n_splits), bool)
     for s in range(n_splits):
-        rng = np.random.default_rng(seed * 1000 + s)
+        rs = np.random.RandomState(seed + s)
         chosen = []
-        for c in np.unique(labels):
+        for c in range(int(labels.max()) + 1 if n else 0):
             idx = np.nonzero(labels == c)[0]
-            chosen.append(rng.choice(idx, size=min(train_per_class, len(idx)), replace=False))
-        chosen = np.concatenate(chosen)
+            chosen.append(rs.choice(idx, min(train_per_class, len(idx)), replace=False) if len(idx) else idx)
+        chosen = np.concatenate(chosen) if chosen else np.zeros(0, np.int64)
+        rest = np.setdiff1d(np.arange(n), chosen)
+        v = rs.choice(rest, min(val_size, len(rest)), replace=False)
         tr[chosen, s] = True
-        rest = rng.permutation(np.setdiff1d(np.arange(n), chosen))
-        v = rest[:min(val_size, len(rest))]
         va[v, s] = True
-        te[rest[len(v):], s] = True
+        te[np.setdiff1d(rest, v), s] = True
     return torch.from_numpy(tr), torch.from_numpy(va), torch.from_numpy(te)
 
 
@@ -70,7 +72,7 @@ def dsbm_cyclic(n_per_cluster=500, clusters=5, p_in=0.1, p_inter=0.1, p_q=0.95, 
     edge_index = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
     y = np.repeat(np.arange(clusters), n_per_cluster)
     x = torch.from_numpy(rng.normal(0, 1.0, (n, 1)).astype(np.float32))
-    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500, seed=seed)
+    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500)      # split s is seeded with s, as in the reference
     return GraphData(x=x, edge_index=edge_index, edge_weight=None, y=torch.from_numpy(y).long(),
                      train_mask=tr, val_mask=va, test_mask=te)
 
@@ -111,7 +113,7 @@ def dsbm(meta='ordered', n_per_cluster=500, clusters=5, p_in=0.1, p_inter=0.1, p
     edge_index = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
     y = np.repeat(np.arange(clusters), m)
     x = torch.from_numpy(rng.normal(0, 1.0, (n, 1)).astype(np.float32))
-    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500, seed=seed)
+    tr, va, te = random_splits(y, train_per_class=train_per_class, val_size=500)      # split s is seeded with s, as in the reference
     return GraphData(x=x, edge_index=edge_index, edge_weight=None, y=torch.from_numpy(y).long(),
                      train_mask=tr, val_mask=va, test_mask=te)
 

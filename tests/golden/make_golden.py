@@ -269,6 +269,37 @@ def telegram_cache():
     print('telegram_cache:', names)
 
 
+def split_cases():
+    """Train / validation / test masks drawn by the reference's own split routine
+    (src/utils/Citation.py:222-246 `train_test_split`) for the CiteSeer labels and for DSBM-shaped labels."""
+    sys.path.insert(0, os.path.join(REF, 'src', 'utils'))
+    for name in ['networkx', 'networkx.algorithms', 'networkx.algorithms.components']:
+        try:
+            __import__(name)
+        except Exception:
+            m = types.ModuleType(name); m.__file__ = '<stub>'; m.__path__ = []
+            sys.modules[name] = m
+    for name in list(sys.modules):
+        if name.startswith(('torch_geometric', 'torch_scatter', 'torch_sparse')):
+            sys.modules[name].__file__ = '<stub>'; sys.modules[name].__path__ = []
+    import Citation
+    z = np.load(os.path.join(REF, 'dataset/data/tmp/citeseer_npz/citeseer_npz.npz'), allow_pickle=False)
+    cases = {'citeseer': (z['labels'].astype(np.int64), 20, 500),
+             'dsbm50': (np.repeat(np.arange(5), 500), 50, 500),
+             'dsbm10': (np.repeat(np.arange(5), 500), 10, 500),
+             'ragged': (np.random.default_rng(3).integers(0, 7, 1500), 20, 300)}
+    out = {'names': np.array(sorted(cases))}
+    for name, (lab, per_class, val) in cases.items():
+        out[name + '/labels'] = lab
+        out[name + '/params'] = np.array([per_class, val])
+        for part in ('train', 'val', 'test'):
+            out[name + '/' + part] = np.stack([Citation.train_test_split(lab, seed=s, train_examples_per_class=per_class,
+                                                                        val_size=val, test_size=None)[part].astype(bool)
+                                               for s in range(10)], axis=1)
+    np.savez_compressed(os.path.join(HERE, 'split_cases.npz'), **out)
+    print('split_cases:', sorted(cases))
+
+
 def config_cases(ref_h, ref_c, ChebNet):
     """One training step (forward, NLL loss on a train mask, backward) of the reference's ChebNet at the
     two small node-classification configurations the benchmark plan names:
@@ -320,6 +351,10 @@ def config_cases(ref_h, ref_c, ChebNet):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'splits':
+        _import_reference()
+        split_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'configs':      # only the (slower) configuration cases
         ref_h, ref_c, ChebConv, ChebNet, ChebNet_Edge = _import_reference()
         config_cases(ref_h, ref_c, ChebNet)
@@ -332,3 +367,4 @@ if __name__ == '__main__':
     net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge)
     citeseer_case(ref_h, ref_c, ChebNet_Edge)
     config_cases(ref_h, ref_c, ChebNet)
+    split_cases()

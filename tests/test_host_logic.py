@@ -237,3 +237,16 @@ def test_load_syn_reads_data_pickles_without_unpickling(tmp_path):
     if os.path.isfile(ref + '.pk'):                       # build container only
         r = D.load_syn(ref)[0]
         assert tuple(r.x.shape) == (2500, 1) and r.edge_index.size(1) == 186984 and int(r.train_mask[:, 0].sum()) == 50
+
+
+def test_random_splits_reproduce_the_reference_draws():
+    """random_splits against masks drawn by the reference's train_test_split (src/utils/Citation.py:222-246)
+    for the CiteSeer labels and DSBM-shaped labels, ten splits each: identical masks."""
+    from magnet_amd.data import random_splits
+    g = load_golden('split_cases.npz')
+    for name in [str(s) for s in g['names']]:
+        per_class, val = (int(v) for v in g[name + '/params'])
+        tr, va, te = random_splits(g[name + '/labels'], 10, per_class, val)
+        assert np.array_equal(tr.numpy(), g[name + '/train']), name
+        assert np.array_equal(va.numpy(), g[name + '/val']), name
+        assert np.array_equal(te.numpy(), g[name + '/test']), name
