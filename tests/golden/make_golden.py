@@ -269,6 +269,27 @@ def telegram_cache():
     print('telegram_cache:', names)
 
 
+def label_cases():
+    """Outputs of the reference's pair-labelling rule for link prediction
+    (src/utils/edge_data.py:122-161 `undirected_label2directed_label`) on a random digraph with
+    reciprocal edges, for the three tasks."""
+    from utils.edge_data import undirected_label2directed_label
+    rng = np.random.default_rng(21)
+    n, e = 120, 900
+    r = rng.integers(0, n, e); c = rng.integers(0, n, e)
+    r = np.concatenate([r, c[:150]]); c = np.concatenate([c, r[:150]])          # some reciprocal pairs
+    A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)).tocsr()
+    A.data[:] = 1.0
+    pairs = np.concatenate([np.stack([r[:500], c[:500]], 1), rng.integers(0, n, (400, 2))]).astype(np.int64)
+    pairs = pairs[rng.permutation(len(pairs))]
+    out = {'row': r, 'col': c, 'n': np.array(n), 'pairs': pairs}
+    for task in (1, 2, 3):
+        p, l = undirected_label2directed_label(A, pairs, task)
+        out['task%d/pairs' % task] = np.asarray(p); out['task%d/label' % task] = np.asarray(l)
+    np.savez_compressed(os.path.join(HERE, 'label_cases.npz'), **out)
+    print('label_cases: %d pairs ->' % len(pairs), [len(out['task%d/label' % t]) for t in (1, 2, 3)])
+
+
 def split_cases():
     """Train / validation / test masks drawn by the reference's own split routine
     (src/utils/Citation.py:222-246 `train_test_split`) for the CiteSeer labels and for DSBM-shaped labels."""
@@ -353,6 +374,7 @@ def config_cases(ref_h, ref_c, ChebNet):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'splits':
         _import_reference()
+        label_cases()
         split_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'configs':      # only the (slower) configuration cases
@@ -367,4 +389,5 @@ if __name__ == '__main__':
     net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge)
     citeseer_case(ref_h, ref_c, ChebNet_Edge)
     config_cases(ref_h, ref_c, ChebNet)
+    label_cases()
     split_cases()

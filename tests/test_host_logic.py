@@ -250,3 +250,17 @@ def test_random_splits_reproduce_the_reference_draws():
         assert np.array_equal(tr.numpy(), g[name + '/train']), name
         assert np.array_equal(va.numpy(), g[name + '/val']), name
         assert np.array_equal(te.numpy(), g[name + '/test']), name
+
+
+def test_pair_labelling_rule_matches_reference():
+    """undirected_label2directed_label against outputs of the reference's function
+    (src/utils/edge_data.py:122-161) for existence, three-class and direction labelling."""
+    import scipy.sparse as sp
+    from magnet_amd.utils.edge_data import undirected_label2directed_label
+    g = load_golden('label_cases.npz')
+    n = int(g['n'])
+    A = sp.coo_matrix((np.ones(len(g['row'])), (g['row'], g['col'])), shape=(n, n)).tocsr()
+    A.data[:] = 1.0
+    for task in (1, 2, 3):
+        p, l = undirected_label2directed_label(A, g['pairs'], task)
+        assert np.array_equal(np.asarray(p), g['task%d/pairs' % task]) and np.array_equal(np.asarray(l), g['task%d/label' % task])
