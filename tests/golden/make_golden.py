@@ -286,6 +286,14 @@ def label_cases():
     for task in (1, 2, 3):
         p, l = undirected_label2directed_label(A, pairs, task)
         out['task%d/pairs' % task] = np.asarray(p); out['task%d/label' % task] = np.asarray(l)
+    # link metrics (src/utils/edge_data.py:538-586) on random three-class log-probabilities
+    from utils.edge_data import link_prediction_evaluation
+    tg = torch.Generator().manual_seed(5)
+    lv = torch.log_softmax(torch.randn(400, 3, generator=tg) * 2, dim=1); lt = torch.log_softmax(torch.randn(300, 3, generator=tg) * 2, dim=1)
+    yv = torch.randint(0, 3, (400,), generator=tg); yt = torch.randint(0, 3, (300,), generator=tg)
+    out['metrics/logp_val'] = lv.numpy(); out['metrics/logp_test'] = lt.numpy()
+    out['metrics/y_val'] = yv.numpy(); out['metrics/y_test'] = yt.numpy()
+    out['metrics/result'] = np.asarray(link_prediction_evaluation(lv, lt, yv, yt), dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, 'label_cases.npz'), **out)
     print('label_cases: %d pairs ->' % len(pairs), [len(out['task%d/label' % t]) for t in (1, 2, 3)])
 

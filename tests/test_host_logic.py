@@ -29,6 +29,11 @@ def test_link_prediction_evaluation():
     assert abs(auc - 0.0) < 1e-12
     assert abs(f1_macro - (2 / 3 + 0.8) / 2) < 1e-12
     assert acc(torch.tensor([1, 0, 1]), torch.tensor([1, 1, 1])) == 2 / 3
+    # against the reference's own function on random three-class outputs
+    g = load_golden('label_cases.npz')
+    got = link_prediction_evaluation(torch.from_numpy(g['metrics/logp_val']), torch.from_numpy(g['metrics/logp_test']),
+                                     torch.from_numpy(g['metrics/y_val']), torch.from_numpy(g['metrics/y_test']))
+    assert np.allclose(np.asarray(got, dtype=np.float64), g['metrics/result'], rtol=1e-12, atol=1e-12)
 
 
 def test_cache_reader_round_trip(tmp_path):
