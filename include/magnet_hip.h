@@ -54,17 +54,23 @@ const char* mh_last_error(void);
  *   mh_lap_build_fill       -> writes col_idx and val from the same workspace
  * The workspace must stay untouched between count and fill.
  * `row`/`col` are int64 when idx64 != 0, else int32.  `weight` may be NULL
- * (every edge has weight 1).  dinv (float[n_nodes], may be NULL in fill only if
- * not wanted back) receives d_i^-1/2.
+ * (every edge has weight 1); `weighted` of mh_lap_workspace_bytes / mh_lap_build_fill
+ * must say whether count was given a non-NULL `weight` (it fixes the workspace
+ * layout).  dinv (float[n_nodes], may be NULL in fill only if not wanted back)
+ * receives d_i^-1/2.
+ * `q` and `max_eigen` are doubles because the reference holds them as Python
+ * floats and rounds 2*pi*q and 2/max_eigen to float32 only when they meet the
+ * float32 matrix (hermitian.py:157,167): rounding q itself first would move
+ * theta by an ulp for values of q that float32 cannot represent.
  */
 size_t mh_lap_workspace_bytes(int64_t n_edges, int32_t n_nodes, int weighted, int gcn_appr);
 
 int mh_lap_build_count(const void* row, const void* col, int idx64, const float* weight,
-                       int64_t n_edges, int32_t n_nodes, float max_eigen, int gcn_appr,
+                       int64_t n_edges, int32_t n_nodes, double max_eigen, int gcn_appr,
                        void* workspace, size_t workspace_bytes,
                        int32_t* row_ptr, int64_t* nnz_host, void* stream);
 
-int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, float q, float max_eigen, int weighted,
+int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, double max_eigen, int weighted,
                       int gcn_appr, void* workspace, size_t workspace_bytes,
                       int64_t nnz /* as returned by count */, int32_t* col_idx, float* val /* [nnz][2] */,
                       float* dinv_out /* [n_nodes] or NULL */, void* stream);

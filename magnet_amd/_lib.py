@@ -23,16 +23,16 @@ def _load():
             'libmagnet_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
             'or `make -C magnet_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    i32, i64, u64, f32, vp, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p, C.c_size_t
+    i32, i64, u64, f32, f64, vp, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
     lib.mh_version.restype = C.c_int
     lib.mh_last_error.restype = C.c_char_p
     lib.mh_lap_workspace_bytes.restype = sz
     lib.mh_lap_workspace_bytes.argtypes = [i64, i32, C.c_int, C.c_int]
     lib.mh_lap_build_count.restype = C.c_int
-    lib.mh_lap_build_count.argtypes = [vp, vp, C.c_int, vp, i64, i32, f32, C.c_int, vp, sz, vp,
+    lib.mh_lap_build_count.argtypes = [vp, vp, C.c_int, vp, i64, i32, f64, C.c_int, vp, sz, vp,
                                        C.POINTER(i64), vp]
     lib.mh_lap_build_fill.restype = C.c_int
-    lib.mh_lap_build_fill.argtypes = [i64, i32, f32, f32, C.c_int, C.c_int, vp, sz, i64, vp, vp, vp, vp]
+    lib.mh_lap_build_fill.argtypes = [i64, i32, f64, f64, C.c_int, C.c_int, vp, sz, i64, vp, vp, vp, vp]
     lib.mh_cspmm.restype = C.c_int
     lib.mh_cspmm.argtypes = [vp, vp, vp, i32,
                              vp, i64, i64,

@@ -334,14 +334,14 @@ extern "C" size_t mh_lap_workspace_bytes(int64_t n_edges, int32_t n_nodes, int w
 }
 
 extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, const float* weight,
-                                  int64_t n_edges, int32_t n_nodes, float max_eigen, int gcn_appr,
+                                  int64_t n_edges, int32_t n_nodes, double max_eigen, int gcn_appr,
                                   void* workspace, size_t workspace_bytes, int32_t* row_ptr,
                                   int64_t* nnz_host, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MH_REQUIRE(n_edges >= 0 && n_nodes >= 0, "negative size");
     MH_REQUIRE(n_edges == 0 || (row && col), "row/col is null");
     MH_REQUIRE(workspace && row_ptr && nnz_host, "workspace/row_ptr/nnz_host is null");
-    MH_REQUIRE(max_eigen > 0.0f, "max_eigen must be positive");
+    MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
     const bool weighted = weight != nullptr, gcn = gcn_appr != 0;
     Layout L = make_layout(n_edges, n_nodes, weighted, gcn);
     if (L.m >= (int64_t(1) << 31) - 1 - n_nodes) return mh::fail(MH_ERR_RANGE, "2*edges does not fit int32 CSR indices");
@@ -359,7 +359,7 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
     int32_t* rec_ptr = reinterpret_cast<int32_t*>(ws + L.off_recptr);
     float* dinv = reinterpret_cast<float*>(ws + L.off_dinv);
     uint32_t* tiles = reinterpret_cast<uint32_t*>(ws + L.off_tiles);
-    const float scale = 2.0f / max_eigen;
+    const float scale = float(2.0 / max_eigen);                 // the double quotient rounded once (hermitian.py:167)
     const int diag = (scale * 1.0f - 1.0f) != 0.0f;
 
     MH_HIP(hipMemsetAsync(hdr, 0, 256, stream));
@@ -417,13 +417,13 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
     return MH_OK;
 }
 
-extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, float q, float max_eigen, int weighted_,
+extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, double max_eigen, int weighted_,
                                  int gcn_appr, void* workspace, size_t workspace_bytes, int64_t nnz,
                                  int32_t* col_idx, float* val, float* dinv_out, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MH_REQUIRE(nnz >= 0, "negative nnz");
     MH_REQUIRE(n_edges >= 0 && n_nodes >= 0 && workspace, "bad size or null workspace");
-    MH_REQUIRE(max_eigen > 0.0f, "max_eigen must be positive");
+    MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
     const bool weighted = weighted_ != 0, gcn = gcn_appr != 0;
     Layout L = make_layout(n_edges, n_nodes, weighted, gcn);
     if (workspace_bytes < L.total)
@@ -435,12 +435,12 @@ extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, float q, floa
     const float* dinv = reinterpret_cast<const float*>(ws + L.off_dinv);
     const float* seg_s = reinterpret_cast<const float*>(ws + L.off_keys0);
     const float* seg_d = seg_s + L.m_pad;
-    const float scale = 2.0f / max_eigen;
+    const float scale = float(2.0 / max_eigen);
     const float diag_val = scale * 1.0f - 1.0f;
     const int diag = diag_val != 0.0f;
     // 2*pi*q as the reference forms it: a double product rounded to fp32 when it meets the
     // float32 matrix (complex64 scalar), hermitian.py:157
-    const float two_pi_q = float(2.0 * 3.14159265358979323846 * double(q));
+    const float two_pi_q = float(2.0 * 3.14159265358979323846 * q);
     if (L.m > 0 && nnz > 0) {
         MH_REQUIRE(col_idx && val, "col_idx/val is null");
         MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");

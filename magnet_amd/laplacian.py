@@ -311,6 +311,8 @@ def build_magnetic_laplacian(row, col, size, q=0.25, max_eigen=2.0, gcn_appr=Fal
         w_t = w_t.reshape(-1).to(torch.float32).to(device).contiguous()
         if w_t.numel() != row_t.numel():
             raise MagnetHipError('edge_weight and row differ in length')
+        if w_t.numel() == 0:
+            w_t = None                      # no edges: an empty tensor has no data pointer to mark the build weighted
     n_edges, n = row_t.numel(), int(size)
     lib = _lib.lib
     with torch.cuda.device(device):

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (not collected by pytest; run by hand on a GPU box):
+
+    python tests/fuzz_parity.py --cases 300 --seed 0
+
+Every case draws a random digraph (sizes, duplicates, self-loops, reciprocal pairs, integer or float
+weights, q, max_eigen, gcn_appr), builds the magnetic Laplacian with the HIP builder and with the oracle
+(structure must be identical, values within 1e-5), then runs one ChebConv forward + backward with random
+widths / order / ReLU against the oracle's fp64 recursion under autograd."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import magnet_oracle as O                      # noqa: E402
+from magnet_amd.utils import hermitian as H                # noqa: E402
+from magnet_amd.layer import sparse_magnet as M            # noqa: E402
+
+
+def close(a, b, rel, what):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    scale = max(float(np.abs(b).max()) if b.size else 0.0, 1e-30)
+    err = float(np.abs(a - b).max()) if b.size else 0.0
+    if err > rel * scale + 1e-7:
+        raise AssertionError('%s: max err %.3e vs scale %.3e' % (what, err, scale))
+
+
+def one_case(rng, idx):
+    n = int(rng.choice([1, 2, 3, 7, 50, 300, 2000, 20000]))
+    e = int(rng.integers(0, 30 * n + 1)) if n > 1 else int(rng.integers(0, 3))
+    row = rng.integers(0, n, e); col = rng.integers(0, n, e)
+    if e > 4:                                              # reciprocal pairs and duplicates on purpose
+        k = e // 4
+        row[:k], col[:k] = col[k:2 * k].copy(), row[k:2 * k].copy()
+        row[2 * k:2 * k + k // 2] = row[:k // 2]; col[2 * k:2 * k + k // 2] = col[:k // 2]
+    kind = rng.integers(0, 3)
+    w = None if kind == 0 else (rng.integers(1, 9, e).astype(np.float32) if kind == 1 else rng.random(e).astype(np.float32))
+    q = float(rng.choice([0.0, 0.05, 0.1, 0.25, 0.5, rng.random() * 0.5]))
+    max_eigen = float(rng.choice([2.0, 2.0, 3.0, 1.5]))
+    gcn = bool(rng.integers(0, 4) == 0)
+    desc = 'n=%d e=%d w=%d q=%r lam=%.1f gcn=%d' % (n, e, kind, q, max_eigen, gcn)
+    Lo = O.hermitian_decomp_sparse(row, col, n, q, max_eigen=max_eigen, gcn_appr=gcn, edge_weight=w)
+    L = H.hermitian_decomp_sparse_device(row, col, n, q, max_eigen=max_eigen, gcn_appr=gcn, edge_weight=w)
+    S = L.to_scipy()
+    Lo.sort_indices()
+    if kind != 2:                                          # float weights: duplicate sums are order dependent in scipy
+        if not (np.array_equal(S.indptr, Lo.indptr) and np.array_equal(S.indices, Lo.indices)):
+            D = (abs(S) > 0).astype(np.int8) - (abs(Lo) > 0).astype(np.int8)
+            D.eliminate_zeros(); D = D.tocoo()
+            extra = [(int(i), int(j), int(v), complex(S[i, j]), complex(Lo[i, j])) for i, j, v in zip(D.row[:5], D.col[:5], D.data[:5])]
+            raise AssertionError('structure %s: nnz %d vs %d, stored-zero counts %d / %d, first differences %s' % (
+                desc, S.nnz, Lo.nnz, int((S.data == 0).sum()), int((Lo.data == 0).sum()), extra))
+        for part, a_, b_ in (('real', S.data.real, Lo.data.real), ('imag', S.data.imag, Lo.data.imag)):
+            try:
+                close(a_, b_, 1e-5, 'L ' + part)
+            except AssertionError as ex:
+                k = int(np.abs(a_ - b_).argmax())
+                r_ = int(np.searchsorted(S.indptr, k, side='right') - 1)
+                raise AssertionError('%s %s: entry (%d,%d) hip %r oracle %r' % (ex, desc, r_, S.indices[k], S.data[k], Lo.data[k]))
+    else:
+        D = (S - Lo).tocoo()
+        close(np.abs(D.data) if D.nnz else np.zeros(1), np.zeros(max(D.nnz, 1)), 0, 'L (float weights)') if D.nnz and np.abs(D.data).max() > 1e-5 * max(np.abs(Lo.data).max(), 1e-30) + 1e-7 else None
+    # one conv, forward + backward
+    K = int(rng.integers(0, 4)); cin = int(rng.choice([1, 2, 3, 4, 8, 17, 32])); cout = int(rng.choice([1, 2, 4, 5, 16, 40]))
+    relu = bool(rng.integers(0, 2))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
+    conv = M.ChebConv(cin, cout, K, H.cheb_poly_sparse(L, K), None).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.3, 0.3)
+    Xr = torch.randn(n, cin, generator=g); Xi = torch.randn(n, cin, generator=g)
+    xr = Xr.cuda().requires_grad_(True); xi = Xi.cuda().requires_grad_(True)
+    p = conv.forward_packed(M._as_packed(xr, xi), relu=relu)
+    Wt = torch.randn(n, 2, cout, generator=g)
+    (p * Wt.cuda()).sum().backward()
+    # oracle in fp64 under autograd (S is the HIP-built matrix: the builder was checked above)
+    Ld = torch.sparse_coo_tensor(np.vstack(S.tocoo().coords), torch.from_numpy(S.tocoo().data.astype(np.complex128)), (n, n)).coalesce()
+    W = conv.weight.detach().cpu().double().requires_grad_(True); b = conv.bias.detach().cpu().double().requires_grad_(True)
+    X = torch.complex(Xr.double(), Xi.double()).requires_grad_(True)
+    zs = [X]
+    if K >= 1:
+        zs.append(torch.sparse.mm(Ld, X))
+    for k in range(2, K + 1):
+        zs.append(2.0 * torch.sparse.mm(Ld, zs[k - 1]) - zs[k - 2])
+    out = sum(z @ W[k].to(torch.complex128) for k, z in enumerate(zs)) + torch.complex(b, b)
+    o_re, o_im = out.real, out.imag
+    if relu:
+        m = (o_re >= 0).double()
+        near = (o_re.abs() < 1e-5 * max(float(o_re.abs().max()), 1e-30))          # sign undecided within rounding
+        if bool(near.any()):
+            return 'skipped (a real part within rounding of zero decides the gate)'
+        o_re, o_im = o_re * m, o_im * m
+    (o_re * Wt[:, 0].double() + o_im * Wt[:, 1].double()).sum().backward()
+    pc = p.detach().cpu()
+    close(pc[:, 0], o_re.detach(), 2e-5, 'out real'); close(pc[:, 1], o_im.detach(), 2e-5, 'out imag')
+    close(conv.weight.grad.cpu(), W.grad, 2e-5, 'dW'); close(conv.bias.grad.cpu(), b.grad, 2e-5, 'db')
+    # d/dX of a real loss wrt complex X: torch returns conj-gradient = dRe + i dIm
+    close(xr.grad.cpu(), X.grad.real, 2e-5, 'dX real'); close(xi.grad.cpu(), X.grad.imag, 2e-5, 'dX imag')
+    return 'ok n=%d e=%d nnz=%d K=%d %d->%d relu=%d w=%d q=%.3f lam=%.1f gcn=%d' % (n, e, L.nnz, K, cin, cout, relu, kind, q, max_eigen, gcn)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=100)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--first', type=int, default=0)
+    a = ap.parse_args()
+    bad = 0
+    for i in range(a.first, a.first + a.cases):
+        rng = np.random.default_rng([a.seed, i])           # every case reproducible on its own (--first i --cases 1)
+        try:
+            msg = one_case(rng, i)
+        except Exception as ex:                            # keep going: report every failing case
+            import traceback
+            bad += 1
+            msg = 'FAILED %r\n%s' % (ex, traceback.format_exc(limit=3))
+        if msg.startswith('FAILED') or i % 20 == 0:
+            print(i, msg, flush=True)
+    print('%d cases, %d failures' % (a.cases, bad), flush=True)
+    sys.exit(1 if bad else 0)

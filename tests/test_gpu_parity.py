@@ -1052,3 +1052,31 @@ def test_conv_block_path_at_full_size():
         # the fused complex ReLU gates both parts on the sign of the conv's own real part
         gated = conv.forward_packed(xp, relu=True, in_block=block)
         assert torch.equal(gated, got * (got[:, 0, :] >= 0).unsqueeze(1))
+
+
+def test_builder_keeps_q_and_max_eigen_in_double():
+    """The reference holds q and max_eigen as Python floats and rounds 2*pi*q and 2/max_eigen to float32
+    only when they meet the float32 matrix.  For a q that float32 cannot represent, rounding q first moves
+    theta by an ulp per unit of weight difference (found by tests/fuzz_parity.py: q = 0.4971724..., weight
+    difference 10 -> 2 ulp of theta, 1.4e-5 relative in the value)."""
+    _, lap, H, M, O = _mods()
+    rng = np.random.default_rng(8)
+    n, e = 500, 4000
+    row = rng.integers(0, n, e); col = rng.integers(0, n, e)
+    w = rng.integers(1, 40, e).astype(np.float32)
+    for q, lam in ((0.49717240448320615, 2.0), (0.1 + 1e-9, 2.1), (1.0 / 3.0, 1.7)):
+        Lo = O.hermitian_decomp_sparse(row, col, n, q, max_eigen=lam, edge_weight=w)
+        L = H.hermitian_decomp_sparse_device(row, col, n, q, max_eigen=lam, edge_weight=w).to_scipy()
+        _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what='q=%r lam=%r' % (q, lam))
+
+
+def test_builder_with_no_edges_and_an_empty_weight_array():
+    """Zero edges with a (zero-length) weight array and max_eigen != 2: the diagonal only.  An empty tensor has
+    no data pointer, which once made the two build phases disagree about the workspace layout."""
+    _, lap, H, M, O = _mods()
+    for n in (1, 2, 9):
+        e = np.zeros(0, np.int64)
+        Lo = O.hermitian_decomp_sparse(e, e, n, 0.3766, max_eigen=1.5, edge_weight=np.zeros(0, np.float32))
+        for _ in range(3):
+            L = H.hermitian_decomp_sparse_device(e, e, n, 0.3766, max_eigen=1.5, edge_weight=np.zeros(0, np.float32)).to_scipy()
+            _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, what='n=%d' % n)
