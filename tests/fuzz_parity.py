@@ -36,6 +36,12 @@ def one_case(rng, idx):
         k = e // 4
         row[:k], col[:k] = col[k:2 * k].copy(), row[k:2 * k].copy()
         row[2 * k:2 * k + k // 2] = row[:k // 2]; col[2 * k:2 * k + k // 2] = col[:k // 2]
+    if n >= 2000 and rng.integers(0, 3) == 0:              # hub rows: long enough for the chunked hub-row path
+        hubs = rng.integers(0, n, 2)
+        extra = int(rng.integers(1500, 6000))
+        hr = np.concatenate([np.full(extra, hubs[0]), rng.integers(0, n, extra)])
+        hc = np.concatenate([rng.integers(0, n, extra), np.full(extra, hubs[1])])
+        row = np.concatenate([row, hr]); col = np.concatenate([col, hc]); e = len(row)
     kind = rng.integers(0, 3)
     w = None if kind == 0 else (rng.integers(1, 9, e).astype(np.float32) if kind == 1 else rng.random(e).astype(np.float32))
     q = float(rng.choice([0.0, 0.05, 0.1, 0.25, 0.5, rng.random() * 0.5]))
@@ -98,7 +104,57 @@ def one_case(rng, idx):
     close(conv.weight.grad.cpu(), W.grad, 2e-5, 'dW'); close(conv.bias.grad.cpu(), b.grad, 2e-5, 'db')
     # d/dX of a real loss wrt complex X: torch returns conj-gradient = dRe + i dIm
     close(xr.grad.cpu(), X.grad.real, 2e-5, 'dX real'); close(xi.grad.cpu(), X.grad.imag, 2e-5, 'dX imag')
-    return 'ok n=%d e=%d nnz=%d K=%d %d->%d relu=%d w=%d q=%.3f lam=%.1f gcn=%d' % (n, e, L.nnz, K, cin, cout, relu, kind, q, max_eigen, gcn)
+    msg = 'ok n=%d e=%d nnz=%d K=%d %d->%d relu=%d w=%d q=%.3f lam=%.1f gcn=%d' % (n, e, L.nnz, K, cin, cout, relu, kind, q, max_eigen, gcn)
+    if n <= 2000 and n >= 3 and max_eigen == 2.0 and not gcn:
+        msg += ' | ' + net_case(rng, row, col, n, q, w, L, S)
+    return msg
+
+
+def net_case(rng, row, col, n, q, w, L, S):
+    """A whole ChebNet or ChebNet_Edge (random depth, width, order, activation) forward + backward against
+    the oracle's restatement of the reference formulation (precomputed sparse T_k, four spmm per order) run
+    under autograd on the CPU."""
+    K = int(rng.integers(1, 4)); layer = int(rng.integers(1, 4)); F = int(rng.choice([1, 2, 4, 8, 16, 20]))
+    cin = int(rng.choice([1, 2, 5, 16])); act = bool(rng.integers(0, 2)); edge = bool(rng.integers(0, 2))
+    ncls = int(rng.integers(2, 5))
+    Ts = O.cheb_poly_sparse(S, K)
+    if sum(t.nnz for t in Ts) > 3_000_000:
+        return 'net skipped (T_k too dense for the CPU oracle)'
+    Lr, Li = O.laplacian_lists(Ts)
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
+    torch.manual_seed(int(rng.integers(0, 2 ** 31)))
+    cls = M.ChebNet_Edge if edge else M.ChebNet
+    net = cls(cin, H.cheb_poly_sparse(L, K), None, num_filter=F, K=K, label_dim=ncls, activation=act, layer=layer, dropout=0.0).cuda()
+    with torch.no_grad():
+        for m in net.Chebs:
+            if hasattr(m, 'bias'):
+                m.bias.uniform_(-0.3, 0.3)
+    state = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    Xr = torch.randn(n, cin, generator=g); Xi = torch.randn(n, cin, generator=g)
+    if edge:
+        m_pairs = int(rng.integers(1, 400))
+        pairs = torch.from_numpy(rng.integers(0, n, (m_pairs, 2)))
+        y = torch.from_numpy(rng.integers(0, ncls, m_pairs))
+        out = net(Xr.cuda(), Xi.cuda(), pairs.cuda())
+        ref = O.chebnet_edge_forward(state, Lr, Li, Xr, Xi, pairs, layer, act)
+        loss, rloss = torch.nn.functional.nll_loss(out, y.cuda()), torch.nn.functional.nll_loss(ref, y)
+    else:
+        y = torch.from_numpy(rng.integers(0, ncls, (1, n)))
+        out = net(Xr.cuda(), Xi.cuda())
+        ref = O.chebnet_forward(state, Lr, Li, Xr, Xi, layer, act)
+        loss, rloss = torch.nn.NLLLoss()(out, y.cuda()), torch.nn.NLLLoss()(ref, y)
+    # a ReLU gate decided within rounding makes the two computations legitimately differ: detect and skip
+    if act and float((out.detach().cpu() - ref.detach()).abs().max()) > 1e-3 * max(float(ref.detach().abs().max()), 1e-30):
+        return 'net skipped (gate decided within rounding)'
+    close(out.detach().cpu(), ref.detach(), 5e-5, 'net out')
+    loss.backward(); rloss.backward()
+    for k, p in net.named_parameters():
+        gr = state[k].grad
+        scale = max(float(gr.abs().max()), 1e-6)
+        if float((p.grad.cpu() - gr).abs().max()) > 2e-4 * scale + 1e-7:
+            raise AssertionError('net grad %s: err %.3e scale %.3e (K=%d layer=%d F=%d cin=%d act=%d edge=%d)' % (
+                k, float((p.grad.cpu() - gr).abs().max()), scale, K, layer, F, cin, act, edge))
+    return 'net ok K=%d layer=%d F=%d cin=%d act=%d edge=%d' % (K, layer, F, cin, act, edge)
 
 
 if __name__ == '__main__':
