@@ -6,7 +6,6 @@ that build it and apply it.
 propagation (the four torch.spmm of reference src/layer/sparse_magnet.py:9-17 in one pass).
 """
 import ctypes as C
-import math
 
 import numpy as np
 import torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config-4 training epoch alone (for rocprofv3 --kernel-trace --stats)."""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Probe: per-order weight GEMMs on separate order matrices vs one GEMM over the orders laid out side
 by side ([N, 2, K+1, F]: each order a strided view the SpMM reads and writes in place)."""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -4,7 +4,6 @@ Run on the GPU box:  python tools/spmm_sweep.py [--quick]"""
 import json
 import os
 import sys
-import time
 
 import torch
 
