@@ -357,6 +357,32 @@ def main():
     watchdog.daemon = True
     watchdog.start()
 
+    # The same conv with the OTHER decomposition (the row partition with its halo exchange per order, when the
+    # headline ran column-sharded): reported beside the headline so that both multi-GPU layouts are on record.
+    if multi and strategy == 'cols' and not args.no_epoch:
+        try:
+            del step
+            layer = None
+            torch.cuda.empty_cache()
+            from magnet_amd.dist import RowPartitionedConv
+            alt = RowPartitionedConv(lap, f, f, K, rank, world, dev)
+            alt.step()
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                alt.step()
+            torch.cuda.synchronize(); dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if out is not None:
+                out['row_partition'] = {'ms_per_step': t.item() / 3 * 1e3, 'edges_per_s': nnz_total * K / (t.item() / 3),
+                                        'note': 'same conv, rows of L and X partitioned, K-1 halo exchanges per conv'}
+            del alt
+        except Exception as ex:
+            if out is not None:
+                out['row_partition'] = {'error': repr(ex)[:300]}
+        step = None
+
     if not args.no_epoch:
         del step, launches
         layer = conv = xp = block = lap = None
