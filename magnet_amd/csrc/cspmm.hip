@@ -50,6 +50,7 @@ struct SpmmArgs {
     const float* bias;
     int relu;
     uint8_t* mask;
+    int64_t mask_ld;             // row stride of the mask (= the full feature width; a column slice keeps it)
     int32_t F;
     // rows longer than long_threshold nonzeros are cut into chunks of `chunk` nonzeros, one wave each
     // (n_long == 0: every row is handled whole by the row kernel)
@@ -197,7 +198,7 @@ __device__ inline void epilogue(const SpmmArgs& a, int r, int64_t foff, float4 a
         if (a.mask) {
             uint32_t bits = (m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 0x100u : 0u) | (m.z != 0.f ? 0x10000u : 0u) |
                             (m.w != 0.f ? 0x1000000u : 0u);
-            *reinterpret_cast<uint32_t*>(a.mask + int64_t(r) * a.F + foff) = bits;
+            *reinterpret_cast<uint32_t*>(a.mask + int64_t(r) * a.mask_ld + foff) = bits;
         }
     }
     float* y = a.Y + int64_t(r) * a.ldy + foff;
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) cspmm_scalar(const SpmmArgs a) {
                 if (a.relu) {
                     float m = yr >= 0.f ? 1.f : 0.f;
                     yr *= m; yi *= m;
-                    if (a.mask) a.mask[int64_t(r) * a.F + f] = m != 0.f ? 1 : 0;
+                    if (a.mask) a.mask[int64_t(r) * a.mask_ld + f] = m != 0.f ? 1 : 0;
                 }
                 float* y = a.Y + int64_t(r) * a.ldy + f;
                 y[0] = yr; y[a.imy] = yi;
@@ -415,7 +416,6 @@ int run_spmm(SpmmArgs a, hipStream_t stream) {
         else launch_vec<64, 4, 1>(a, stream);
     } else if (vec) {
         // wider than one pass: column slices of 1024 features, each a full pass over the CSR
-        if (a.mask) return mh::fail(MH_ERR_ARG, "mask_out is not supported for F > 1024");
         for (int32_t f0 = 0; f0 < F; f0 += 1024) {
             SpmmArgs s = a;
             int32_t fw = F - f0 < 1024 ? F - f0 : 1024;
@@ -423,6 +423,7 @@ int run_spmm(SpmmArgs a, hipStream_t stream) {
             if (a.Z1) s.Z1 = a.Z1 + f0;
             if (a.Z2) s.Z2 = a.Z2 + f0;
             if (a.bias) s.bias = a.bias + f0;
+            if (a.mask) s.mask = a.mask + f0;
             int nvec = fw >> 2;
             if (nvec <= 64) launch_vec<64, 1, 4>(s, stream);
             else if (nvec <= 128) launch_vec<64, 2, 2>(s, stream);
@@ -462,7 +463,7 @@ extern "C" int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, 
     a.Y = Y; a.ldy = ldy; a.imy = imy; a.alpha = alpha;
     a.Z1 = Z1; a.ldz1 = ldz1; a.imz1 = imz1; a.beta1 = beta1;
     a.Z2 = Z2; a.ldz2 = ldz2; a.imz2 = imz2; a.beta2 = beta2;
-    a.bias = bias; a.relu = relu; a.mask = relu ? mask_out : nullptr; a.F = F;
+    a.bias = bias; a.relu = relu; a.mask = relu ? mask_out : nullptr; a.mask_ld = F; a.F = F;
     if (plan && n_long > 0) {
         MH_REQUIRE(n_chunks >= n_long && chunk >= 64, "bad plan sizes: n_long=%d n_chunks=%d chunk=%d", n_long, n_chunks, chunk);
         MH_REQUIRE(scratch != nullptr, "scratch is null");

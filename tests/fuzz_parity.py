@@ -110,6 +110,64 @@ def one_case(rng, idx):
     return msg
 
 
+def spmm_case(rng):
+    """One fused SpMM call with random shape, feature width, operand strides, axpy operands (also aliasing
+    the output), bias, ReLU + mask, against a complex128 computation on the host."""
+    import scipy.sparse as sp
+    from magnet_amd.laplacian import MagneticLaplacian
+    n_rows = int(rng.choice([1, 5, 64, 700, 5000])); n_cols = int(rng.choice([1, 9, 300, 5000]))
+    dens = float(rng.choice([0.0, 0.01, 0.2, 1.0]))
+    nnz_target = min(int(dens * n_rows * n_cols) + int(rng.integers(0, 3)), 400_000)
+    r = rng.integers(0, n_rows, nnz_target); c = rng.integers(0, n_cols, nnz_target)
+    if n_rows >= 700 and rng.integers(0, 2):                # a hub row for the chunked path
+        extra = int(rng.integers(1100, 5000)); r = np.concatenate([r, np.full(extra, rng.integers(0, n_rows))]); c = np.concatenate([c, rng.integers(0, n_cols, extra)])
+    A = sp.coo_matrix(((rng.standard_normal(len(r)) + 1j * rng.standard_normal(len(r))).astype(np.complex64), (r, c)), shape=(n_rows, n_cols)).tocsr()
+    A.sum_duplicates(); A.sort_indices()
+    L = MagneticLaplacian.from_scipy(A)
+    F = int(rng.choice([1, 2, 3, 4, 8, 12, 20, 64, 100, 256, 260, 1028, 1100]))
+    if n_rows * F > 4_000_000 or n_cols * F > 4_000_000:
+        F = 4
+    pad = int(rng.choice([0, 0, 4, 5])); gap = int(rng.choice([0, 0, 8, 3]))
+
+    def alloc(rows):                                         # row-planar with a padded row stride and a gap before the imaginary part
+        im = F + gap; ld = im + F + pad
+        buf = torch.randn(rows * ld + 8, device='cuda')
+        return torch.as_strided(buf, (rows, 2, F), (ld, im, 1), int(rng.choice([0, 4])))
+    X = alloc(n_cols); Y = alloc(n_rows)
+    use1, use2 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    alias = use1 and bool(rng.integers(0, 3) == 0)
+    Z1 = (Y if alias else alloc(n_rows)) if use1 else None
+    Z2 = alloc(n_rows) if use2 else None
+    alpha, b1, b2 = float(rng.choice([1.0, 2.0, -0.5])), float(rng.choice([1.0, -1.0, 0.25])), float(rng.choice([-1.0, 0.5]))
+    bias = torch.randn(F, device='cuda') if rng.integers(0, 2) else None
+    relu = bool(rng.integers(0, 2))
+    mask = torch.empty((n_rows, F), dtype=torch.uint8, device='cuda') if relu and rng.integers(0, 2) else None
+    cx = lambda t: t[:, 0, :].double().cpu().numpy() + 1j * t[:, 1, :].double().cpu().numpy()
+    want = alpha * (A.astype(np.complex128) @ cx(X))
+    if use1:
+        want = want + b1 * cx(Z1)
+    if use2:
+        want = want + b2 * cx(Z2)
+    if bias is not None:
+        bb = bias.double().cpu().numpy(); want = want + bb + 1j * bb
+    L.spmm(X, out=Y, alpha=alpha, z1=Z1, beta1=b1, z2=Z2, beta2=b2, bias=bias, relu=relu, mask=mask)
+    got = cx(Y)
+    scale = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
+    if relu:
+        undecided = np.abs(want.real) < 1e-5 * scale
+        m = want.real >= 0
+        want = want * m
+        got = np.where(undecided, want, got)
+        if mask is not None:
+            mk = mask.cpu().numpy().astype(bool)
+            assert np.array_equal(mk[~undecided], m[~undecided]), 'mask'
+    err = float(np.abs(got - want).max()) if want.size else 0.0
+    if err > 2e-5 * scale + 1e-7:
+        raise AssertionError('spmm: err %.3e scale %.3e (rows=%d cols=%d nnz=%d F=%d pad=%d gap=%d z1=%d alias=%d z2=%d bias=%d relu=%d)' % (
+            err, scale, n_rows, n_cols, A.nnz, F, pad, gap, use1, alias, use2, bias is not None, relu))
+    return 'spmm ok rows=%d cols=%d nnz=%d F=%d' % (n_rows, n_cols, A.nnz, F)
+
+
 def net_case(rng, row, col, n, q, w, L, S):
     """A whole ChebNet or ChebNet_Edge (random depth, width, order, activation) forward + backward against
     the oracle's restatement of the reference formulation (precomputed sparse T_k, four spmm per order) run
@@ -162,12 +220,13 @@ if __name__ == '__main__':
     ap.add_argument('--cases', type=int, default=100)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--first', type=int, default=0)
+    ap.add_argument('--kind', choices=['graph', 'spmm'], default='graph')
     a = ap.parse_args()
     bad = 0
     for i in range(a.first, a.first + a.cases):
         rng = np.random.default_rng([a.seed, i])           # every case reproducible on its own (--first i --cases 1)
         try:
-            msg = one_case(rng, i)
+            msg = spmm_case(rng) if a.kind == 'spmm' else one_case(rng, i)
         except Exception as ex:                            # keep going: report every failing case
             import traceback
             bad += 1

@@ -210,7 +210,7 @@ def test_spmm_feature_widths(small_graph, f):
     _spmm_case(L, Ls, f, seed=f)
 
 
-@pytest.mark.parametrize('f', [4, 16, 128, 256, 6])
+@pytest.mark.parametrize('f', [4, 16, 128, 256, 6, 1100])          # 1100: wider than one pass, mask written per column slice
 def test_spmm_epilogues(small_graph, f):
     L, Ls = small_graph
     _spmm_case(L, Ls, f, 1, alpha=2.0, use_z1=True)
