@@ -168,6 +168,44 @@ def spmm_case(rng):
     return 'spmm ok rows=%d cols=%d nnz=%d F=%d' % (n_rows, n_cols, A.nnz, F)
 
 
+def aux_case(rng):
+    """Layout / activation / row-staging kernels with random shapes and strides against torch."""
+    from magnet_amd import laplacian as lapmod
+    n = int(rng.choice([0, 1, 7, 300, 5000])); F = int(rng.choice([1, 2, 3, 4, 8, 20, 64, 130, 1028]))
+    pad, gap = int(rng.choice([0, 4, 3])), int(rng.choice([0, 8, 5]))
+
+    def alloc(rows):
+        im = F + gap; ld = im + F + pad
+        buf = torch.randn(rows * ld + 8, device='cuda')
+        return torch.as_strided(buf, (rows, 2, F), (ld, im, 1), int(rng.choice([0, 4])))
+    re = torch.randn(n, F + 3, device='cuda')[:, :F]; im_ = torch.randn(n, F, device='cuda')
+    p = lapmod.pack_complex(re, im_, out=alloc(n))
+    assert torch.equal(p[:, 0, :], re) and torch.equal(p[:, 1, :], im_), 'pack'
+    r2, i2 = lapmod.unpack_complex(p)
+    assert torch.equal(r2, re) and torch.equal(i2, im_), 'unpack'
+    if n:
+        bias = torch.randn(F, device='cuda')
+        want = p.clone() + bias.view(1, 1, F)
+        m = (want[:, 0, :] >= 0)
+        want = want * m.unsqueeze(1)
+        q_ = p.clone() if rng.integers(0, 2) else alloc(n).copy_(p)
+        mask = M._bias_relu_(q_, bias, True)
+        assert torch.equal(q_, want) and torch.equal(mask.bool(), m), 'bias_relu'
+        g = alloc(n)
+        g0 = g.clone()
+        M._relu_bwd_(g, mask)
+        assert torch.equal(g, g0 * m.unsqueeze(1)), 'relu_bwd'
+        k = int(rng.integers(0, n + 1))
+        idx = torch.from_numpy(rng.permutation(n)[:k].astype(np.int32)).cuda()
+        buf = lapmod.gather_rows(p, idx)
+        assert torch.equal(buf, p[idx.long()]), 'gather_rows'
+        tgt = alloc(n); t0 = tgt.clone()
+        lapmod.scatter_rows(buf, idx, tgt)
+        t0[idx.long()] = buf
+        assert torch.equal(tgt, t0), 'scatter_rows'
+    return 'aux ok n=%d F=%d' % (n, F)
+
+
 def net_case(rng, row, col, n, q, w, L, S):
     """A whole ChebNet or ChebNet_Edge (random depth, width, order, activation) forward + backward against
     the oracle's restatement of the reference formulation (precomputed sparse T_k, four spmm per order) run
@@ -220,13 +258,13 @@ if __name__ == '__main__':
     ap.add_argument('--cases', type=int, default=100)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--first', type=int, default=0)
-    ap.add_argument('--kind', choices=['graph', 'spmm'], default='graph')
+    ap.add_argument('--kind', choices=['graph', 'spmm', 'aux'], default='graph')
     a = ap.parse_args()
     bad = 0
     for i in range(a.first, a.first + a.cases):
         rng = np.random.default_rng([a.seed, i])           # every case reproducible on its own (--first i --cases 1)
         try:
-            msg = spmm_case(rng) if a.kind == 'spmm' else one_case(rng, i)
+            msg = spmm_case(rng) if a.kind == 'spmm' else aux_case(rng) if a.kind == 'aux' else one_case(rng, i)
         except Exception as ex:                            # keep going: report every failing case
             import traceback
             bad += 1
