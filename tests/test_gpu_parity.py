@@ -1080,3 +1080,29 @@ def test_builder_with_no_edges_and_an_empty_weight_array():
         for _ in range(3):
             L = H.hermitian_decomp_sparse_device(e, e, n, 0.3766, max_eigen=1.5, edge_weight=np.zeros(0, np.float32)).to_scipy()
             _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, what='n=%d' % n)
+
+
+def test_integration_stub_from_the_docs_runs():
+    """The ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would paste next to
+    utils/hermitian.py) is executed as it stands: builder and one propagation order against the oracle."""
+    import re
+    _, lap, H, M, O = _mods()
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if 'mh_lap_build_count.argtypes' in b]
+    assert len(stub) == 1
+    code = stub[0].replace('"magnet_amd/csrc/libmagnet_hip.so"', repr(_mods()[0]._lib.LIB_PATH))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    row, col, n, _ = _telegram(0.25, False)
+    r = torch.from_numpy(row).cuda(); c = torch.from_numpy(col).cuda()
+    row_ptr, col_idx, val = ns['hermitian_decomp_sparse_gpu'](r, c, n, 0.25)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.25)
+    assert np.array_equal(row_ptr.cpu().numpy(), Lo.indptr) and np.array_equal(col_idx.cpu().numpy(), Lo.indices)
+    v = val.cpu().numpy()
+    assert_close(v[:, 0], Lo.data.real); assert_close(v[:, 1], Lo.data.imag)
+    X = torch.randn(n, 2, 12, device=DEV); Z = torch.randn(n, 2, 12, device=DEV)
+    Y = ns['propagate'](row_ptr, col_idx, val, X, alpha=2.0, Z=Z, beta=-1.0)
+    cx = lambda t: t[:, 0, :].double().cpu().numpy() + 1j * t[:, 1, :].double().cpu().numpy()
+    want = 2.0 * (Lo.astype(np.complex128) @ cx(X)) - cx(Z)
+    assert_close(cx(Y).real, want.real); assert_close(cx(Y).imag, want.imag)
