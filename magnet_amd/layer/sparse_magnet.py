@@ -28,6 +28,7 @@ order 0 of the next conv's block.  All sparse work, bias and the complex ReLU ru
 GPU only.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -211,6 +212,11 @@ def _clenshaw(lap, ys, bias=None, relu=False, n_terms=None, out=None):
 # recurrence (a 10M-node, 256-feature, K=3 block would be 80 GB).
 FUSED_BACKWARD_BYTES = 8 << 30
 
+# Memory for time at graph scale: a conv whose block of saved orders would exceed this many bytes keeps only
+# its input for the backward pass and recomputes T_k(L) X there (K more SpMMs per conv and training step).
+# 0 = never (default); e.g. 32 GiB lets a 3-layer, 256-filter, K=3 net train on the 10M-node graph on one GPU.
+RECOMPUTE_ORDERS_BYTES = int(os.environ.get('MH_RECOMPUTE_ORDERS_BYTES', '0'))
+
 
 class _ChebConvFn(torch.autograd.Function):
     """out = sum_k T_k(L) X W_k + bias (+ complex ReLU), L Hermitian.
@@ -251,6 +257,13 @@ class _ChebConvFn(torch.autograd.Function):
             else:                                          # the bias rides on the GEMM's epilogue
                 torch.addmm(b.reshape(1, cout), _block_rows(block), w.reshape(k1 * cin, cout), out=o2)
             mask = _bias_relu_(out, None, relu)
+        ctx.x0 = None
+        if (block is not None and not orders_ready and RECOMPUTE_ORDERS_BYTES > 0
+                and 8 * n * k1 * cin > RECOMPUTE_ORDERS_BYTES and ctx.needs_input_grad[1]):
+            # keep the input only (a compact copy when it is order 0 of a handed-over block, which would
+            # otherwise pin the whole block) and let the block go
+            ctx.x0 = xp if in_block is None else xp.clone(memory_format=torch.contiguous_format)
+            block = None
         ctx.lap, ctx.relu, ctx.gemm_first, ctx.has_bias = lap, relu, gemm_first, bias is not None
         ctx.mask = mask
         ctx.block = block
@@ -290,8 +303,10 @@ class _ChebConvFn(torch.autograd.Function):
                 db = g.sum(dim=(0, 1)).view(1, cout)
             g2 = _rows2(g)
             if need_w:
-                dw = _gram(_block_rows(ctx.block), g2).view(k1, cin, cout)
-            ctx.block = None                               # the saved orders are not needed past this point
+                block = ctx.block if ctx.block is not None else _cheb_terms(lap, ctx.x0, k1)   # recomputed orders
+                dw = _gram(_block_rows(block), g2).view(k1, cin, cout)
+                block = None
+            ctx.block = ctx.x0 = None                      # the saved orders are not needed past this point
             if need_x:
                 if 8 * n * k1 * cin <= FUSED_BACKWARD_BYTES:
                     ys = torch.mm(g2, w.permute(2, 0, 1).reshape(cout, k1 * cin)).view(n, 2, k1, cin)
@@ -623,6 +638,8 @@ def _run_trunk(chebs, real, imag):
             step = 2 if fuse else 1
             nxt = mods[i + step] if i + step < len(mods) else None
             next_terms = nxt._n_terms if isinstance(nxt, ChebConv) and nxt._spmm_first() else 0
+            if next_terms and 0 < RECOMPUTE_ORDERS_BYTES < 8 * real.size(0) * next_terms * nxt.weight.size(1):
+                next_terms = 0     # over the memory budget: blocks live one at a time, so none is allocated ahead
             if p is None:
                 p = m.forward_first(real, imag, relu=fuse, next_terms=next_terms)
             else:

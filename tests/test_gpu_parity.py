@@ -1132,3 +1132,29 @@ def test_backward_fused_and_lazy_clenshaw_agree():
         M.FUSED_BACKWARD_BYTES = saved
     for a, b in zip(grads['fused'], grads['lazy']):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def test_recomputed_orders_give_the_same_gradients():
+    """RECOMPUTE_ORDERS_BYTES: convs whose saved orders exceed the budget keep only their input and redo the
+    K SpMMs in the backward pass — bit-identical gradients, in a network with block hand-over."""
+    _, lap, H, M, O = _mods()
+    row, col, n, _ = _telegram(0.25, False)
+    L = H.hermitian_decomp_sparse_device(row, col, n, 0.25)
+    torch.manual_seed(41)
+    net = M.ChebNet(6, H.cheb_poly_sparse(L, 2), None, num_filter=8, K=2, label_dim=4, activation=True, layer=3).to(DEV)
+    X = torch.randn(n, 6, device=DEV); y = torch.randint(0, 4, (1, n), device=DEV)
+    saved, saved_cache = M.RECOMPUTE_ORDERS_BYTES, M.ChebConv.cache_input_propagation
+    res = {}
+    try:
+        M.ChebConv.cache_input_propagation = False
+        for tag, budget in (('kept', 0), ('recomputed', 1)):
+            M.RECOMPUTE_ORDERS_BYTES = budget
+            net.zero_grad()
+            xr = X.clone().requires_grad_(True)
+            out = net(xr, X)
+            torch.nn.NLLLoss()(out, y).backward()
+            res[tag] = [out.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    finally:
+        M.RECOMPUTE_ORDERS_BYTES, M.ChebConv.cache_input_propagation = saved, saved_cache
+    for a, b in zip(res['kept'], res['recomputed']):
+        assert torch.equal(a, b)

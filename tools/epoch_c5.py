@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Does a 2-layer ChebNet train on the config-5 graph (10M nodes / 200M edges, 256 features, K=3) on ONE GPU?"""
+"""Does a ChebNet (LAYERS=2 by default) train on the config-5 graph (10M nodes / 200M edges, 256 features, K=3) on
+ONE GPU?  MH_RECOMPUTE_ORDERS_BYTES=<bytes> trades K SpMMs per conv for the memory of the saved orders."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ src, dst = powerlaw_edges(n, e, 43, device=dev)
 lap = build_magnetic_laplacian(src, dst, n, q=0.25)
 del src, dst
 torch.cuda.empty_cache()
-net = ChebNet(f, ChebBasis(lap, K), None, num_filter=f, K=K, label_dim=5, activation=True, layer=2).to(dev)
+net = ChebNet(f, ChebBasis(lap, K), None, num_filter=f, K=K, label_dim=5, activation=True, layer=int(os.environ.get('LAYERS', 2))).to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
 X = torch.randn(n, f, device=dev); y = torch.randint(0, 5, (1, n), device=dev)
 tr = (torch.rand(n, device=dev) < 0.6).nonzero().squeeze(1); va = torch.arange(0, n, 7, device=dev)
