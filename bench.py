@@ -246,9 +246,10 @@ def main():
         from magnet_amd.dist import RowPartitionedConv, ColumnShardedConv
         strategy = args.strategy
         if strategy == 'auto':
-            # K <= 1 needs no exchange in the row partition; otherwise a graph without locality moves
-            # (K-1)*world/(K+1) times fewer bytes when feature columns are sharded instead
-            strategy = 'cols' if (K >= 2 and f % (4 * world) == 0) else 'rows'
+            # K <= 1 needs no exchange in the row partition and a graph with id locality only its boundary
+            # rows; a graph without locality moves (K-1)*world/(K+1) times fewer bytes column-sharded
+            from magnet_amd.dist import choose_strategy
+            strategy = choose_strategy(lap.row_ptr, lap.col_idx, n, f, K, world)
         if strategy == 'cols':
             layer = ColumnShardedConv(lap, f, f, K, rank, world, dev)
         else:

@@ -125,6 +125,32 @@ class HipRowMover:
         scatter_rows(buf, idx, x)
 
 
+def exchange_volumes(row_ptr, col_idx, n, n_features, K, world):
+    """Feature floats one rank sends per conv under the two decompositions, largest rank:
+    (row partition: K-1 exchanges of the rows its peers reference; column sharding: one all-to-all of the
+    K+1 orders).  Plain tensor code, every rank computes the same numbers from the replicated CSR."""
+    bounds = partition_bounds(row_ptr, world)
+    rows_worst = 0
+    for p in range(world):
+        a, b = int(row_ptr[bounds[p]]), int(row_ptr[bounds[p + 1]])
+        cols = col_idx[a:b]
+        remote = torch.unique(cols[(cols < bounds[p]) | (cols >= bounds[p + 1])])   # rows of other ranks that rank p gathers
+        rows_worst = max(rows_worst, int(remote.numel()))
+    rows_floats = max(K - 1, 0) * rows_worst * 2 * n_features       # received (= sent by symmetry of the pattern, at worst)
+    cols_floats = (K + 1) * n * 2 * n_features * (world - 1) // (world * world)
+    return rows_floats, cols_floats
+
+
+def choose_strategy(row_ptr, col_idx, n, n_features, K, world):
+    """'rows' or 'cols' for a conv on `world` GPUs: the row partition needs no exchange at all for K <= 1
+    and little on graphs whose neighbours have nearby ids (only boundary rows travel); on a graph without
+    locality every row is a boundary row and column sharding moves (K-1) world / (K+1) times less."""
+    if world == 1 or K <= 1 or n_features % (4 * world) != 0:
+        return 'rows'
+    rows_floats, cols_floats = exchange_volumes(row_ptr, col_idx, n, n_features, K, world)
+    return 'rows' if rows_floats <= cols_floats else 'cols'
+
+
 class RowPartition:
     """The rank's share of a Laplacian: its row block split into local-column and remote-column
     parts, and the exchange of freshly computed rows.  `make_operator(rp, ci, val, n_cols)` turns CSR

@@ -270,3 +270,18 @@ def test_split_columns_and_slice_rows():
     assert bool(((cii >= r0) & (cii < r1)).all()) and bool(((cie < r0) | (cie >= r1)).all())
     a = ScipyOperator(rpi, cii, vi, n).m + ScipyOperator(rpe, cie, ve, n).m
     assert abs(a - sub.astype(np.complex128)).max() < 1e-7
+
+
+def test_choose_strategy_follows_the_exchange_volume():
+    """Row partition when it needs no or little exchange (K <= 1, graphs whose neighbours have nearby ids),
+    column sharding on a graph without locality."""
+    L, rp, ci, val = _graph(n=4000, e=60000)
+    assert D.choose_strategy(rp, ci, 4000, 64, 3, 4) == 'cols'
+    assert D.choose_strategy(rp, ci, 4000, 64, 1, 4) == 'rows'          # no exchange at all
+    assert D.choose_strategy(rp, ci, 4000, 6, 3, 4) == 'rows'           # columns do not split into float4 slices
+    assert D.choose_strategy(rp, ci, 4000, 64, 3, 1) == 'rows'
+    Lb, rpb, cib, valb = _banded_graph(n=4000, reach=6)
+    r, c = D.exchange_volumes(rpb, cib, 4000, 64, 3, 4)
+    assert r < c / 10 and D.choose_strategy(rpb, cib, 4000, 64, 3, 4) == 'rows'
+    r, c = D.exchange_volumes(rp, ci, 4000, 64, 3, 4)
+    assert r > c
