@@ -1083,8 +1083,9 @@ def test_builder_with_no_edges_and_an_empty_weight_array():
 
 
 def test_integration_stub_from_the_docs_runs():
-    """The ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would paste next to
-    utils/hermitian.py) is executed as it stands: builder and one propagation order against the oracle."""
+    """The ctypes stub printed in the integration guide at the repository root (what a maintainer of the
+    reference would paste next to utils/hermitian.py) is executed as it stands: builder and one propagation
+    order against the oracle."""
     import re
     _, lap, H, M, O = _mods()
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
