@@ -104,23 +104,23 @@ def undirected_label2directed_label(adj, edge_pairs, task):
     labelled alternately 0 (listed along the edge) and 1 (listed against it), reciprocal pairs are
     dropped, absent pairs get 2; for the existence tasks (task != 2) absent pairs become class 1
     and class 1 is thinned to the size of class 0 with default_rng(1000)."""
-    labels = np.zeros(len(edge_pairs), dtype=np.int32)
-    new_edge_pairs = np.array(edge_pairs).copy()
-    counter = 0
-    for i, e in enumerate(edge_pairs):
-        fwd, bwd = adj[e[0], e[1]] > 0, adj[e[1], e[0]] > 0
-        if fwd or bwd:
-            if fwd and bwd:
-                labels[i] = -1
-                continue
-            along = [e[0], e[1]] if fwd else [e[1], e[0]]
-            if counter % 2 == 0:
-                labels[i] = 0; new_edge_pairs[i] = along
-            else:
-                labels[i] = 1; new_edge_pairs[i] = along[::-1]
-            counter += 1
-        else:
-            labels[i] = 2
+    pairs = np.asarray(edge_pairs).reshape(-1, 2)
+    a, b = pairs[:, 0], pairs[:, 1]
+    if len(pairs):
+        fwd = np.asarray(adj[a, b]).ravel() > 0
+        bwd = np.asarray(adj[b, a]).ravel() > 0
+    else:
+        fwd = bwd = np.zeros(0, bool)
+    one_way = fwd ^ bwd
+    labels = np.full(len(pairs), 2, dtype=np.int32)            # absent pairs
+    labels[fwd & bwd] = -1                                      # reciprocal pairs are dropped
+    order = np.cumsum(one_way) - 1                              # running count over the one-way pairs, in list order
+    labels[one_way] = (order[one_way] % 2).astype(np.int32)     # alternately 0 (along the edge) and 1 (against it)
+    new_edge_pairs = pairs.copy()
+    along = np.where(fwd[:, None], pairs, pairs[:, ::-1])       # the pair listed along its edge
+    sel0, sel1 = one_way & (labels == 0), one_way & (labels == 1)
+    new_edge_pairs[sel0] = along[sel0]
+    new_edge_pairs[sel1] = along[sel1][:, ::-1]
     if task != 2:
         labels[labels == 2] = 1
         neg = np.where(labels == 1)[0]
@@ -159,12 +159,12 @@ def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15,
         ids_val, labels_val = undirected_label2directed_label(A, ids_val, task)
         _, ids_train = _split_undirected(g_val, size, 0.99, ind, False)
         ids_train, labels_train = undirected_label2directed_label(A, ids_train, task)
+        # back to the stored direction (reference :197-203; a reciprocal pair ends up listed as (b, a))
+        ab = np.asarray(A[g_val[:, 0], g_val[:, 1]]).ravel() > 0 if len(g_val) else np.zeros(0, bool)
+        ba = np.asarray(A[g_val[:, 1], g_val[:, 0]]).ravel() > 0 if len(g_val) else np.zeros(0, bool)
         observed = np.zeros((len(g_val), 2), dtype=np.int32)
-        for i, (a, b) in enumerate(g_val.tolist()):        # back to the stored direction (reference :197-203)
-            if A[a, b] > 0:
-                observed[i] = [a, b]
-            if A[b, a] > 0:
-                observed[i] = [b, a]
+        observed[ab] = g_val[ab]
+        observed[ba] = g_val[ba][:, ::-1]
         if label_dim == 2:
             ids_train, labels_train = ids_train[labels_train < 2], labels_train[labels_train < 2]
             ids_test, labels_test = ids_test[labels_test < 2], labels_test[labels_test < 2]
