@@ -86,6 +86,17 @@ def stream_ceilings(dev, nbytes=8 << 30, iters=5):
             'read': 1.0 * nbytes * iters / (ev[1].elapsed_time(ev[2]) * 1e-3) / 1e9}
 
 
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(args):
     """The reference formulation (uncoalesced COO, four real spmm per order) on the host cores,
     on a bounded sample of the same workload."""
@@ -130,6 +141,7 @@ def cpu_baseline(args):
         'builder_edges_per_s': e / t_build,
         'builder_note': 'numpy restatement of hermitian_decomp_sparse, 1 thread, %.2f s' % t_build,
         'host_cpu_count': os.cpu_count(),
+        'cpu_model': _cpu_model(),
     }
 
 
