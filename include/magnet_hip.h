@@ -128,6 +128,27 @@ int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, const float
                      const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
                      float* scratch, size_t scratch_bytes, void* stream);
 
+/* mh_cspmm_planned for callers that cannot allocate device memory (code under HIP graph capture,
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and results as mh_cspmm_planned, without `scratch`: the hub-row partial sums go to a buffer of
+ * MH_NOALLOC_SCRATCH_BYTES that is built into the library (one per GPU, held until the process ends).
+ * The call allocates nothing.  It fails with MH_ERR_WORKSPACE when n_chunks * 2 * F * 4 bytes exceed the
+ * built-in buffer.  The device that owns `stream` must be the current device.  All calls on one GPU share
+ * that GPU's buffer: calls that overlap in time on one GPU (different streams or threads) race; calls
+ * ordered on one stream do not.  Nothing of an earlier call is read: every chunk slot is written before
+ * it is combined.
+ */
+#define MH_NOALLOC_SCRATCH_BYTES (64u << 20)
+int mh_cspmm_planned_noalloc(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n_rows,
+                             const float* X, int64_t ldx, int64_t imx,
+                             float* Y, int64_t ldy, int64_t imy,
+                             float alpha,
+                             const float* Z1, int64_t ldz1, int64_t imz1, float beta1,
+                             const float* Z2, int64_t ldz2, int64_t imz2, float beta2,
+                             const float* bias, int relu, uint8_t* mask_out, int32_t F,
+                             const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
+                             void* stream);
+
 /* Whole recursions in one call (the loop over orders of ChebConv.forward,
  * src/layer/sparse_magnet.py:60-68, with the polynomials of src/utils/hermitian.py:117-134
  * applied to features instead of being formed).  Matrices are contiguous row-planar

@@ -42,6 +42,8 @@ def _load():
                              vp, C.c_int, vp, i32, vp]
     lib.mh_cspmm_planned.restype = C.c_int
     lib.mh_cspmm_planned.argtypes = lib.mh_cspmm.argtypes[:-1] + [vp, i32, i32, i32, vp, sz, vp]
+    lib.mh_cspmm_planned_noalloc.restype = C.c_int
+    lib.mh_cspmm_planned_noalloc.argtypes = lib.mh_cspmm.argtypes[:-1] + [vp, i32, i32, i32, vp]
     lib.mh_cspmm_plan_ints.restype = sz
     lib.mh_cspmm_plan_ints.argtypes = [i32, i32]
     lib.mh_cspmm_plan_count.restype = C.c_int
@@ -77,7 +79,7 @@ lib = _load()
 EXPORTS = [
     'mh_version', 'mh_last_error',
     'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
-    'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
+    'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
     'mh_cheb_terms', 'mh_clenshaw',
     'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd',
     'mh_powerlaw_edges', 'mh_stream_read',

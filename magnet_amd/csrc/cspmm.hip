@@ -27,10 +27,16 @@
 // No float atomics, fixed summation order: results are bitwise reproducible.
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+
+// Hub-row partial sums of mh_cspmm_planned_noalloc: one copy of this array lives on every GPU the
+// library is loaded on, from module load until the process ends.  Host code never uses the name as
+// an address; static_scratch() resolves the per-device address once with hipGetSymbolAddress.
+static __device__ __align__(256) float scratch[MH_NOALLOC_SCRATCH_BYTES / sizeof(float)];
 
 namespace {
 
@@ -476,6 +482,55 @@ extern "C" int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, 
         a.scratch = scratch;
     }
     return run_spmm(a, stream);
+}
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+float* g_static_scratch[kMaxDevices];      // device address of `scratch` on each GPU, resolved on first use
+std::mutex g_static_scratch_mu;
+
+// address of this GPU's copy of `scratch` (the current device's)
+int static_scratch(float** out) {
+    int dev = -1;
+    MH_HIP(hipGetDevice(&dev));
+    MH_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside [0, %d)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_static_scratch_mu);
+    if (!g_static_scratch[dev]) {
+        void* p = nullptr;
+        MH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        MH_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
+        g_static_scratch[dev] = static_cast<float*>(p);
+    }
+    *out = g_static_scratch[dev];
+    return MH_OK;
+}
+
+}  // namespace
+
+extern "C" int mh_cspmm_planned_noalloc(const int32_t* row_ptr, const int32_t* col_idx, const float* val,
+                                        int32_t n_rows, const float* X, int64_t ldx, int64_t imx, float* Y,
+                                        int64_t ldy, int64_t imy, float alpha, const float* Z1, int64_t ldz1,
+                                        int64_t imz1, float beta1, const float* Z2, int64_t ldz2, int64_t imz2,
+                                        float beta2, const float* bias, int relu, uint8_t* mask_out, int32_t F,
+                                        const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
+                                        void* stream_) {
+    float* ptr = nullptr;
+    size_t need = 0;
+    if (plan && n_long > 0) {
+        MH_REQUIRE(n_chunks >= n_long && F >= 1, "bad plan sizes: n_long=%d n_chunks=%d F=%d", n_long, n_chunks, F);
+        need = size_t(n_chunks) * 2 * size_t(F) * sizeof(float);
+        if (need > size_t(MH_NOALLOC_SCRATCH_BYTES))
+            return mh::fail(MH_ERR_WORKSPACE,
+                            "hub-row partial sums need %zu bytes, the built-in scratch holds %zu (n_chunks=%d, F=%d): "
+                            "use mh_cspmm_planned with caller memory", need, size_t(MH_NOALLOC_SCRATCH_BYTES), n_chunks, F);
+        int rc = static_scratch(&ptr);
+        if (rc != MH_OK) return rc;
+    }
+    // every chunk's slot is written by the chunk kernel before the combine kernel reads it on the same
+    // stream, so nothing left over from an earlier call is ever read and nothing needs clearing
+    return mh_cspmm_planned(row_ptr, col_idx, val, n_rows, X, ldx, imx, Y, ldy, imy, alpha, Z1, ldz1, imz1, beta1, Z2,
+                            ldz2, imz2, beta2, bias, relu, mask_out, F, plan, n_long, n_chunks, chunk, ptr, need, stream_);
 }
 
 extern "C" int mh_cspmm(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n_rows,
