@@ -71,8 +71,7 @@ def stream_ceilings(dev, nbytes=8 << 30, iters=5):
     from magnet_amd import _lib
     a = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev); b = torch.empty_like(a)
     sink = torch.zeros(1, device=dev)
-    stream = _lib.stream_ptr(dev)
-    read = lambda: _lib.check(_lib.lib.mh_stream_read(_lib.ptr(a), nbytes, _lib.ptr(sink), stream))
+    read = lambda: _lib.ops.stream_read(a, sink)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     b.copy_(a); read()
     ev[0].record()

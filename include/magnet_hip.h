@@ -193,6 +193,26 @@ int mh_gather_rows(const float* X, int64_t ld, int64_t im, const int32_t* idx, i
 int mh_scatter_rows(const float* buf, const int32_t* idx, int64_t n_idx,
                     float* X, int64_t ld, int64_t im, int32_t F, void* stream);
 
+/* Halo plan of one rank's row block (row-partitioned propagation over several GPUs; no counterpart in the
+ * single-device reference, src/sparse_Magnet.py:23-24).  The block's col_idx[nnz] holds GLOBAL column ids in
+ * [0, n_cols); the rank owns columns [c0, c1).  From the column ids alone:
+ *   halo_ids [n_halo]   ascending global ids of the referenced columns outside [c0, c1): the feature rows that
+ *                       must arrive from peers before the block's SpMM can gather them;
+ *   peer_ptr [world+1]  halo_ids[peer_ptr[p] : peer_ptr[p+1]] are owned by peer p, whose rows are
+ *                       bounds[p] .. bounds[p+1] (bounds: device int32[world+1], ascending, bounds[world] = n_cols);
+ *   col_local [nnz]     columns renumbered for a compact feature buffer [own rows | halo rows]:
+ *                       own c -> c - c0, remote c -> (c1 - c0) + slot of c in halo_ids.
+ * Two phases because n_halo is data dependent: count marks and scans (SYNCHRONISES stream, returns n_halo),
+ * fill writes the three outputs (each may be NULL when not wanted) from the same, untouched workspace of
+ * mh_halo_plan_workspace_bytes(n_cols) bytes.
+ */
+size_t mh_halo_plan_workspace_bytes(int32_t n_cols);
+int mh_halo_plan_count(const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t c0, int32_t c1,
+                       void* workspace, size_t workspace_bytes, int64_t* n_halo_host, void* stream);
+int mh_halo_plan_fill(const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t c0, int32_t c1,
+                      const int32_t* bounds, int32_t world, void* workspace, size_t workspace_bytes, int64_t n_halo,
+                      int32_t* halo_ids, int32_t* peer_ptr, int32_t* col_local, void* stream);
+
 /* In place on row-planar Y: add bias[F] to both parts (NULL = none), then the
  * complex ReLU when relu != 0, storing the mask when mask_out != NULL.
  * src/layer/sparse_magnet.py:72 and :79-81. */

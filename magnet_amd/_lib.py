@@ -1,20 +1,26 @@
-"""ctypes binding of libmagnet_hip.so (declared in include/magnet_hip.h).
+"""Bindings of the native code.
 
-The library is the product path: if it is missing the import fails loudly; there
-is no CPU fallback.  Device pointers come from torch tensors (torch is only the
-allocator / stream owner here).
+`ops`  — the product path: torch.ops.magnet.* of libmagnet_torch.so, the thin PyTorch-ROCm C++
+         extension (csrc/torch_ext.cpp) that takes tensors, checks them, and forwards raw device
+         pointers + the current torch stream to the C ABI of libmagnet_hip.so (include/magnet_hip.h).
+`lib`  — the same C ABI bound directly with ctypes: what a caller without torch would bind, used
+         here for the ABI checks and by the tests that call entry points with raw pointers.
+
+Both libraries are built in-tree; if either is missing the import fails loudly.  There is no CPU
+fallback: the operators are registered for the GPU dispatch key only.
 """
 import ctypes as C
 import os
 
 import torch
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmagnet_hip.so')
-
-
 class MagnetHipError(RuntimeError):
     pass
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmagnet_hip.so')
+EXT_PATH = os.path.join(_HERE, 'csrc', 'libmagnet_torch.so')
 
 
 def _load():
@@ -60,6 +66,12 @@ def _load():
     lib.mh_gather_rows.argtypes = [vp, i64, i64, vp, i64, vp, i32, vp]
     lib.mh_scatter_rows.restype = C.c_int
     lib.mh_scatter_rows.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
+    lib.mh_halo_plan_workspace_bytes.restype = sz
+    lib.mh_halo_plan_workspace_bytes.argtypes = [i32]
+    lib.mh_halo_plan_count.restype = C.c_int
+    lib.mh_halo_plan_count.argtypes = [vp, i64, i32, i32, i32, vp, sz, C.POINTER(i64), vp]
+    lib.mh_halo_plan_fill.restype = C.c_int
+    lib.mh_halo_plan_fill.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, sz, i64, vp, vp, vp, vp]
     lib.mh_pack.restype = C.c_int
     lib.mh_pack.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i32, vp]
     lib.mh_bias_relu.restype = C.c_int
@@ -75,12 +87,46 @@ def _load():
 
 lib = _load()
 
+# operators the extension registers (csrc/torch_ext.cpp)
+OPS = ['cspmm', 'cspmm_noalloc', 'plan_build', 'cheb_terms_', 'clenshaw', 'lap_build', 'pack', 'unpack',
+       'gather_rows', 'scatter_rows', 'bias_relu_', 'relu_bwd_', 'halo_plan', 'powerlaw_edges', 'stream_read',
+       'version']
+
+
+def _guarded(op):
+    """The operator with its errors raised as MagnetHipError (a RuntimeError, as the extension throws them)."""
+    def call(*args):
+        try:
+            return op(*args)
+        except NotImplementedError as e:            # no kernel for that backend: CPU tensors
+            raise MagnetHipError('magnet_amd runs on the GPU only: %s' % str(e).split('\n')[0]) from None
+        except RuntimeError as e:
+            raise MagnetHipError(str(e).split('\nException raised from')[0]) from None
+    call.__name__ = getattr(op, '__name__', 'op')
+    return call
+
+
+class _Ops:
+    def __init__(self):
+        if not os.path.exists(EXT_PATH):
+            raise ImportError(
+                'libmagnet_torch.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+                'or `make -C magnet_amd/csrc`. There is no CPU fallback.' % EXT_PATH)
+        torch.ops.load_library(EXT_PATH)
+        ns = torch.ops.magnet
+        for name in OPS:
+            setattr(self, name, _guarded(getattr(ns, name).default))
+
+
+ops = _Ops()
+
 # every symbol include/magnet_hip.h declares (tests/test_abi_cpu.py compares the two lists)
 EXPORTS = [
     'mh_version', 'mh_last_error',
     'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
     'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
     'mh_cheb_terms', 'mh_clenshaw',
+    'mh_halo_plan_workspace_bytes', 'mh_halo_plan_count', 'mh_halo_plan_fill',
     'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd',
     'mh_powerlaw_edges', 'mh_stream_read',
 ]

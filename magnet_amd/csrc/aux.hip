@@ -22,7 +22,7 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace mh
 
-extern "C" int mh_version(void) { return 100; }
+extern "C" int mh_version(void) { return 200; }
 extern "C" const char* mh_last_error(void) { return mh::error_buffer(); }
 
 namespace {

@@ -1,0 +1,401 @@
+// Thin PyTorch-ROCm extension over the C ABI of libmagnet_hip.so (include/magnet_hip.h).
+//
+// Registers the operators of the MagNet propagation path in the torch dispatcher (namespace
+// `magnet`, CUDA = HIP dispatch key).  Each operator checks tensor types and shapes, takes raw
+// device pointers, strides and the CURRENT torch stream of the operand's device, forwards them to
+// the corresponding mh_* entry point and turns a non-zero return code into a RuntimeError that
+// carries mh_last_error().  torch is the allocator and the stream owner; no arithmetic happens here.
+//
+// The reference reaches this path through Python calls into torch.sparse
+// (reference src/layer/sparse_magnet.py:8-18,50-72) and scipy (src/utils/hermitian.py:136-168);
+// `torch.ops.magnet.*` are the calls that replace them.
+#include <cstdint>
+#include <tuple>
+
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../include/magnet_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = c10::optional<at::Tensor>;
+
+void check_rc(int rc, const char* what) {
+    TORCH_CHECK(rc == MH_OK, "libmagnet_hip error ", rc, " in ", what, ": ", mh_last_error());
+}
+
+void* stream_of(const Tensor& t) {
+    return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+void need_cuda(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), "magnet_amd runs on the GPU only: ", name, " is a ", t.device().str(), " tensor");
+}
+
+const int32_t* i32(const Tensor& t, const char* name) {
+    need_cuda(t, name);
+    TORCH_CHECK(t.scalar_type() == at::kInt && t.is_contiguous(), name, " must be a contiguous int32 tensor");
+    return t.data_ptr<int32_t>();
+}
+
+// a row-planar complex matrix [N, 2, F] float32 whose feature dimension is contiguous
+struct Planar {
+    float* p = nullptr;
+    int64_t ld = 0, im = 0, n = 0, f = 0;
+};
+
+Planar planar(const Tensor& t, const char* name) {
+    need_cuda(t, name);
+    TORCH_CHECK(t.dim() == 3 && t.size(1) == 2 && t.scalar_type() == at::kFloat, name, " must be float32 [N, 2, F], got ",
+                t.scalar_type(), " ", t.sizes());
+    TORCH_CHECK(t.size(2) <= 1 || t.stride(2) == 1, name, ": feature dimension must be contiguous");
+    Planar r;
+    r.p = t.data_ptr<float>(); r.ld = t.stride(0); r.im = t.stride(1); r.n = t.size(0); r.f = t.size(2);
+    return r;
+}
+
+Planar planar_opt(const OptTensor& t, const char* name, int64_t n, int64_t f) {
+    if (!t.has_value() || !t->defined()) return Planar{};
+    Planar r = planar(*t, name);
+    TORCH_CHECK(r.n == n && r.f == f, name, " has shape ", t->sizes(), ", expected (", n, ", 2, ", f, ")");
+    return r;
+}
+
+struct Csr {
+    const int32_t* row_ptr; const int32_t* col_idx; const float* val;
+    int64_t n_rows, nnz;
+};
+
+Csr csr(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val) {
+    Csr c;
+    c.row_ptr = i32(row_ptr, "row_ptr"); c.col_idx = i32(col_idx, "col_idx");
+    need_cuda(val, "val");
+    TORCH_CHECK(val.scalar_type() == at::kFloat && val.is_contiguous() && val.numel() == 2 * col_idx.numel(),
+                "val must be contiguous float32 [nnz, 2]");
+    c.val = val.data_ptr<float>();
+    c.n_rows = row_ptr.numel() - 1; c.nnz = col_idx.numel();
+    TORCH_CHECK(c.n_rows >= 0 && c.n_rows <= INT32_MAX, "row_ptr must hold n_rows + 1 entries");
+    return c;
+}
+
+struct Plan {
+    const int32_t* plan = nullptr; int32_t n_long = 0, n_chunks = 0, chunk = 0;
+    float* scratch = nullptr; size_t scratch_bytes = 0;
+};
+
+Plan plan_of(const OptTensor& plan, int64_t n_long, int64_t n_chunks, int64_t chunk, const OptTensor& scratch) {
+    Plan p;
+    if (!plan.has_value() || !plan->defined() || n_long <= 0) return p;
+    p.plan = i32(*plan, "plan");
+    TORCH_CHECK(size_t(plan->numel()) >= mh_cspmm_plan_ints(int32_t(n_long), int32_t(n_chunks)), "plan tensor too short");
+    p.n_long = int32_t(n_long); p.n_chunks = int32_t(n_chunks); p.chunk = int32_t(chunk);
+    if (scratch.has_value() && scratch->defined()) {
+        need_cuda(*scratch, "scratch");
+        TORCH_CHECK(scratch->scalar_type() == at::kFloat && scratch->is_contiguous(), "scratch must be contiguous float32");
+        p.scratch = scratch->data_ptr<float>(); p.scratch_bytes = size_t(scratch->numel()) * sizeof(float);
+    }
+    return p;
+}
+
+const float* bias_of(const OptTensor& bias, int64_t f) {
+    if (!bias.has_value() || !bias->defined()) return nullptr;
+    need_cuda(*bias, "bias");
+    TORCH_CHECK(bias->scalar_type() == at::kFloat && bias->is_contiguous() && bias->numel() == f, "bias must be contiguous float32 with ",
+                f, " entries, got ", bias->sizes());
+    return bias->data_ptr<float>();
+}
+
+uint8_t* mask_of(const OptTensor& mask, int64_t n, int64_t f) {
+    if (!mask.has_value() || !mask->defined()) return nullptr;
+    need_cuda(*mask, "mask");
+    TORCH_CHECK(mask->scalar_type() == at::kByte && mask->is_contiguous() && mask->numel() == n * f,
+                "mask must be contiguous uint8 [n_rows, F]");
+    return mask->data_ptr<uint8_t>();
+}
+
+// ---- one propagation order ---------------------------------------------------------------------
+void cspmm_impl(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val, int64_t n_cols, const Tensor& X, Tensor& Y,
+                double alpha, const OptTensor& Z1, double beta1, const OptTensor& Z2, double beta2, const OptTensor& bias,
+                bool relu, const OptTensor& mask, const OptTensor& plan, int64_t n_long, int64_t n_chunks, int64_t chunk,
+                const OptTensor& scratch, bool noalloc) {
+    const c10::DeviceGuard guard(X.device());
+    Csr c = csr(row_ptr, col_idx, val);
+    Planar x = planar(X, "X"), y = planar(Y, "out");
+    TORCH_CHECK(x.n == n_cols, "X has ", x.n, " rows, the Laplacian has ", n_cols, " columns");
+    TORCH_CHECK(y.n == c.n_rows && y.f == x.f, "out has shape ", Y.sizes(), ", expected (", c.n_rows, ", 2, ", x.f, ")");
+    Planar z1 = planar_opt(Z1, "z1", c.n_rows, x.f), z2 = planar_opt(Z2, "z2", c.n_rows, x.f);
+    const float* b = bias_of(bias, x.f);
+    uint8_t* m = mask_of(mask, c.n_rows, x.f);
+    Plan p = plan_of(plan, n_long, n_chunks, chunk, scratch);
+    int rc;
+    if (noalloc)
+        rc = mh_cspmm_planned_noalloc(c.row_ptr, c.col_idx, c.val, int32_t(c.n_rows), x.p, x.ld, x.im, y.p, y.ld, y.im, float(alpha),
+                                      z1.p, z1.ld, z1.im, float(beta1), z2.p, z2.ld, z2.im, float(beta2), b, relu ? 1 : 0, m,
+                                      int32_t(x.f), p.plan, p.n_long, p.n_chunks, p.chunk, stream_of(X));
+    else
+        rc = mh_cspmm_planned(c.row_ptr, c.col_idx, c.val, int32_t(c.n_rows), x.p, x.ld, x.im, y.p, y.ld, y.im, float(alpha),
+                              z1.p, z1.ld, z1.im, float(beta1), z2.p, z2.ld, z2.im, float(beta2), b, relu ? 1 : 0, m,
+                              int32_t(x.f), p.plan, p.n_long, p.n_chunks, p.chunk, p.scratch, p.scratch_bytes, stream_of(X));
+    check_rc(rc, "cspmm");
+}
+
+void cspmm(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val, int64_t n_cols, const Tensor& X, Tensor& Y,
+           double alpha, const OptTensor& Z1, double beta1, const OptTensor& Z2, double beta2, const OptTensor& bias, bool relu,
+           const OptTensor& mask, const OptTensor& plan, int64_t n_long, int64_t n_chunks, int64_t chunk,
+           const OptTensor& scratch) {
+    cspmm_impl(row_ptr, col_idx, val, n_cols, X, Y, alpha, Z1, beta1, Z2, beta2, bias, relu, mask, plan, n_long, n_chunks, chunk,
+               scratch, false);
+}
+
+void cspmm_noalloc(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val, int64_t n_cols, const Tensor& X, Tensor& Y,
+                   double alpha, const OptTensor& Z1, double beta1, const OptTensor& Z2, double beta2, const OptTensor& bias,
+                   bool relu, const OptTensor& mask, const OptTensor& plan, int64_t n_long, int64_t n_chunks, int64_t chunk) {
+    cspmm_impl(row_ptr, col_idx, val, n_cols, X, Y, alpha, Z1, beta1, Z2, beta2, bias, relu, mask, plan, n_long, n_chunks, chunk,
+               OptTensor(), true);
+}
+
+// hub-row plan of a CSR: (plan tensor, n_long, n_chunks); an empty tensor when no row is long
+std::tuple<Tensor, int64_t, int64_t> plan_build(const Tensor& row_ptr, int64_t chunk) {
+    const c10::DeviceGuard guard(row_ptr.device());
+    const int32_t* rp = i32(row_ptr, "row_ptr");
+    const int64_t n_rows = row_ptr.numel() - 1;
+    auto opts = row_ptr.options();
+    Tensor counters = at::empty({2}, opts);
+    int32_t n_long = 0, n_chunks = 0;
+    check_rc(mh_cspmm_plan_count(rp, int32_t(n_rows), int32_t(chunk), counters.data_ptr<int32_t>(), &n_long, &n_chunks,
+                                 stream_of(row_ptr)), "cspmm_plan_count");
+    if (n_long == 0) return std::make_tuple(at::empty({0}, opts), int64_t(0), int64_t(0));
+    Tensor plan = at::empty({int64_t(mh_cspmm_plan_ints(n_long, n_chunks))}, opts);
+    check_rc(mh_cspmm_plan_fill(rp, int32_t(n_rows), int32_t(chunk), n_long, n_chunks, plan.data_ptr<int32_t>(),
+                                stream_of(row_ptr)), "cspmm_plan_fill");
+    return std::make_tuple(plan, int64_t(n_long), int64_t(n_chunks));
+}
+
+// ---- whole recursions --------------------------------------------------------------------------
+void cheb_terms_(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val, Tensor& Z, const OptTensor& plan,
+                 int64_t n_long, int64_t n_chunks, int64_t chunk, const OptTensor& scratch) {
+    const c10::DeviceGuard guard(Z.device());
+    Csr c = csr(row_ptr, col_idx, val);
+    need_cuda(Z, "Z");
+    TORCH_CHECK(Z.dim() == 4 && Z.size(2) == 2 && Z.is_contiguous() && Z.scalar_type() == at::kFloat && Z.size(1) == c.n_rows,
+                "Z must be contiguous float32 [n_terms, N, 2, F] with N = the Laplacian's row count");
+    Plan p = plan_of(plan, n_long, n_chunks, chunk, scratch);
+    check_rc(mh_cheb_terms(c.row_ptr, c.col_idx, c.val, int32_t(c.n_rows), Z.data_ptr<float>(), Z.stride(0), int32_t(Z.size(0)),
+                           int32_t(Z.size(3)), p.plan, p.n_long, p.n_chunks, p.chunk, p.scratch, p.scratch_bytes, stream_of(Z)),
+             "cheb_terms");
+}
+
+void clenshaw(const Tensor& row_ptr, const Tensor& col_idx, const Tensor& val, const Tensor& Y, const OptTensor& work, Tensor& out,
+              const OptTensor& bias, bool relu, const OptTensor& mask, const OptTensor& plan, int64_t n_long, int64_t n_chunks,
+              int64_t chunk, const OptTensor& scratch) {
+    const c10::DeviceGuard guard(Y.device());
+    Csr c = csr(row_ptr, col_idx, val);
+    need_cuda(Y, "Y");
+    TORCH_CHECK(Y.dim() == 4 && Y.size(2) == 2 && Y.is_contiguous() && Y.scalar_type() == at::kFloat && Y.size(1) == c.n_rows,
+                "y must be contiguous float32 [n_terms, N, 2, F] with N = the Laplacian's row count");
+    const int64_t k1 = Y.size(0), n = Y.size(1), f = Y.size(3);
+    need_cuda(out, "out");
+    TORCH_CHECK(out.is_contiguous() && out.scalar_type() == at::kFloat && out.numel() == n * 2 * f, "out must be contiguous [N, 2, F]");
+    float* w = nullptr;
+    if (work.has_value() && work->defined()) {
+        need_cuda(*work, "work");
+        TORCH_CHECK(work->is_contiguous() && work->scalar_type() == at::kFloat && work->numel() >= 2 * n * 2 * f,
+                    "work must hold two [N, 2, F] matrices");
+        w = work->data_ptr<float>();
+    }
+    Plan p = plan_of(plan, n_long, n_chunks, chunk, scratch);
+    check_rc(mh_clenshaw(c.row_ptr, c.col_idx, c.val, int32_t(n), Y.data_ptr<float>(), Y.stride(0), int32_t(k1), w,
+                         out.data_ptr<float>(), bias_of(bias, f), relu ? 1 : 0, mask_of(mask, n, f), int32_t(f), p.plan, p.n_long,
+                         p.n_chunks, p.chunk, p.scratch, p.scratch_bytes, stream_of(Y)), "clenshaw");
+}
+
+// ---- Laplacian builder -------------------------------------------------------------------------
+// (row_ptr, col_idx, val [nnz, 2], dinv) of the magnetic Laplacian of the edge list
+std::tuple<Tensor, Tensor, Tensor, Tensor> lap_build(const Tensor& row, const Tensor& col, const OptTensor& weight,
+                                                     int64_t n_nodes, double q, double max_eigen, bool gcn_appr) {
+    need_cuda(row, "row"); need_cuda(col, "col");
+    const c10::DeviceGuard guard(row.device());
+    TORCH_CHECK(row.scalar_type() == col.scalar_type() && (row.scalar_type() == at::kInt || row.scalar_type() == at::kLong),
+                "row and col must both be int32 or both int64");
+    TORCH_CHECK(row.is_contiguous() && col.is_contiguous() && row.dim() == 1 && row.numel() == col.numel(),
+                "row and col must be contiguous vectors of equal length");
+    TORCH_CHECK(n_nodes >= 0 && n_nodes <= INT32_MAX, "n_nodes out of range");
+    const int64_t n_edges = row.numel();
+    const float* w = nullptr;
+    if (weight.has_value() && weight->defined() && weight->numel() > 0) {
+        need_cuda(*weight, "edge_weight");
+        TORCH_CHECK(weight->scalar_type() == at::kFloat && weight->is_contiguous() && weight->numel() == n_edges,
+                    "edge_weight must be contiguous float32 of the edge count");
+        w = weight->data_ptr<float>();
+    }
+    const int weighted = w != nullptr, gcn = gcn_appr ? 1 : 0;
+    const size_t ws_bytes = mh_lap_workspace_bytes(n_edges, int32_t(n_nodes), weighted, gcn);
+    auto bytes = row.options().dtype(at::kByte);
+    auto ints = row.options().dtype(at::kInt);
+    auto floats = row.options().dtype(at::kFloat);
+    Tensor ws = at::empty({int64_t(ws_bytes)}, bytes);
+    Tensor row_ptr = at::empty({n_nodes + 1}, ints);
+    int64_t nnz = 0;
+    void* s = stream_of(row);
+    check_rc(mh_lap_build_count(row.data_ptr(), col.data_ptr(), row.scalar_type() == at::kLong, w, n_edges, int32_t(n_nodes),
+                                max_eigen, gcn, ws.data_ptr(), ws_bytes, row_ptr.data_ptr<int32_t>(), &nnz, s), "lap_build_count");
+    Tensor col_idx = at::empty({nnz}, ints);
+    Tensor val = at::empty({nnz, 2}, floats);
+    Tensor dinv = at::empty({n_nodes}, floats);
+    check_rc(mh_lap_build_fill(n_edges, int32_t(n_nodes), q, max_eigen, weighted, gcn, ws.data_ptr(), ws_bytes, nnz,
+                               col_idx.data_ptr<int32_t>(), val.data_ptr<float>(), dinv.data_ptr<float>(), s), "lap_build_fill");
+    return std::make_tuple(row_ptr, col_idx, val, dinv);
+}
+
+// ---- layout / activation -----------------------------------------------------------------------
+void pack(const Tensor& real, const Tensor& imag, Tensor& out) {
+    const c10::DeviceGuard guard(out.device());
+    need_cuda(real, "real"); need_cuda(imag, "imag");
+    TORCH_CHECK(real.dim() == 2 && real.sizes() == imag.sizes() && real.scalar_type() == at::kFloat && imag.scalar_type() == at::kFloat,
+                "real/imag must be float32 [N, F] of equal shape, got ", real.sizes(), " and ", imag.sizes());
+    TORCH_CHECK((real.size(1) <= 1 || real.stride(1) == 1) && (imag.size(1) <= 1 || imag.stride(1) == 1),
+                "real/imag: feature dimension must be contiguous");
+    Planar o = planar(out, "out");
+    TORCH_CHECK(o.n == real.size(0) && o.f == real.size(1), "out has shape ", out.sizes());
+    check_rc(mh_pack(real.data_ptr<float>(), real.stride(0), imag.data_ptr<float>(), imag.stride(0), o.p, o.ld, o.im, o.n,
+                     int32_t(o.f), stream_of(out)), "pack");
+}
+
+void unpack(const Tensor& p, Tensor& re, Tensor& im) {
+    const c10::DeviceGuard guard(p.device());
+    Planar x = planar(p, "p");
+    need_cuda(re, "re"); need_cuda(im, "im");
+    TORCH_CHECK(re.is_contiguous() && im.is_contiguous() && re.scalar_type() == at::kFloat && im.scalar_type() == at::kFloat &&
+                re.numel() == x.n * x.f && im.numel() == x.n * x.f, "re/im must be contiguous float32 [N, F]");
+    check_rc(mh_unpack(x.p, x.ld, x.im, re.data_ptr<float>(), x.f, im.data_ptr<float>(), x.f, x.n, int32_t(x.f), stream_of(p)),
+             "unpack");
+}
+
+void gather_rows(const Tensor& x, const Tensor& idx, Tensor& buf) {
+    const c10::DeviceGuard guard(x.device());
+    Planar a = planar(x, "x");
+    const int32_t* ix = i32(idx, "idx");
+    need_cuda(buf, "buf");
+    TORCH_CHECK(buf.is_contiguous() && buf.scalar_type() == at::kFloat && buf.numel() == idx.numel() * 2 * a.f,
+                "buf must be contiguous [len(idx), 2, F]");
+    check_rc(mh_gather_rows(a.p, a.ld, a.im, ix, idx.numel(), buf.data_ptr<float>(), int32_t(a.f), stream_of(x)), "gather_rows");
+}
+
+void scatter_rows(const Tensor& buf, const Tensor& idx, Tensor& x) {
+    const c10::DeviceGuard guard(x.device());
+    Planar a = planar(x, "x");
+    const int32_t* ix = i32(idx, "idx");
+    need_cuda(buf, "buf");
+    TORCH_CHECK(buf.is_contiguous() && buf.scalar_type() == at::kFloat && buf.numel() == idx.numel() * 2 * a.f,
+                "buf must be contiguous [len(idx), 2, F]");
+    check_rc(mh_scatter_rows(buf.data_ptr<float>(), ix, idx.numel(), a.p, a.ld, a.im, int32_t(a.f), stream_of(x)), "scatter_rows");
+}
+
+void bias_relu_(Tensor& Y, const OptTensor& bias, bool relu, const OptTensor& mask) {
+    const c10::DeviceGuard guard(Y.device());
+    Planar y = planar(Y, "Y");
+    check_rc(mh_bias_relu(y.p, y.ld, y.im, bias_of(bias, y.f), relu ? 1 : 0, mask_of(mask, y.n, y.f), y.n, int32_t(y.f), stream_of(Y)),
+             "bias_relu");
+}
+
+void relu_bwd_(Tensor& G, const Tensor& mask) {
+    const c10::DeviceGuard guard(G.device());
+    Planar g = planar(G, "G");
+    check_rc(mh_relu_bwd(g.p, g.ld, g.im, mask_of(mask, g.n, g.f), g.n, int32_t(g.f), stream_of(G)), "relu_bwd");
+}
+
+// ---- halo plan of a row block ------------------------------------------------------------------
+// (halo_ids [n_halo] ascending global column ids outside [c0, c1) that the block references,
+//  peer_ptr [world + 1]: halo_ids[peer_ptr[p] : peer_ptr[p+1]] lie in rows bounds[p] .. bounds[p+1] of peer p,
+//  col_local [nnz]: columns renumbered to [own columns - c0 | n_own + halo slot])
+std::tuple<Tensor, Tensor, Tensor> halo_plan(const Tensor& col_idx, int64_t n_cols, int64_t c0, int64_t c1, const Tensor& bounds) {
+    const c10::DeviceGuard guard(col_idx.device());
+    const int32_t* ci = i32(col_idx, "col_idx");
+    const int32_t* b = i32(bounds, "bounds");
+    const int64_t world = bounds.numel() - 1;
+    TORCH_CHECK(world >= 1 && n_cols >= 0 && n_cols <= INT32_MAX, "bad halo plan sizes");
+    auto ints = col_idx.options();
+    const size_t ws_bytes = mh_halo_plan_workspace_bytes(int32_t(n_cols));
+    Tensor ws = at::empty({int64_t(ws_bytes)}, ints.dtype(at::kByte));
+    int64_t n_halo = 0;
+    void* s = stream_of(col_idx);
+    check_rc(mh_halo_plan_count(ci, col_idx.numel(), int32_t(n_cols), int32_t(c0), int32_t(c1), ws.data_ptr(), ws_bytes, &n_halo, s),
+             "halo_plan_count");
+    Tensor halo_ids = at::empty({n_halo}, ints);
+    Tensor peer_ptr = at::empty({world + 1}, ints);
+    Tensor col_local = at::empty({col_idx.numel()}, ints);
+    check_rc(mh_halo_plan_fill(ci, col_idx.numel(), int32_t(n_cols), int32_t(c0), int32_t(c1), b, int32_t(world), ws.data_ptr(),
+                               ws_bytes, n_halo, halo_ids.data_ptr<int32_t>(), peer_ptr.data_ptr<int32_t>(),
+                               col_local.data_ptr<int32_t>(), s), "halo_plan_fill");
+    return std::make_tuple(halo_ids, peer_ptr, col_local);
+}
+
+// ---- generator / measurement aid ---------------------------------------------------------------
+void powerlaw_edges(int64_t n_nodes, int64_t seed, int64_t first_edge, Tensor& src, Tensor& dst) {
+    const c10::DeviceGuard guard(src.device());
+    need_cuda(src, "src"); need_cuda(dst, "dst");
+    TORCH_CHECK(src.scalar_type() == at::kInt && dst.scalar_type() == at::kInt && src.is_contiguous() && dst.is_contiguous() &&
+                src.numel() == dst.numel(), "src/dst must be contiguous int32 of equal length");
+    check_rc(mh_powerlaw_edges(int32_t(n_nodes), src.numel(), uint64_t(seed), first_edge, src.data_ptr<int32_t>(),
+                               dst.data_ptr<int32_t>(), stream_of(src)), "powerlaw_edges");
+}
+
+void stream_read(const Tensor& buf, Tensor& sink) {
+    const c10::DeviceGuard guard(buf.device());
+    need_cuda(buf, "buf"); need_cuda(sink, "sink");
+    TORCH_CHECK(buf.is_contiguous() && sink.scalar_type() == at::kFloat && sink.numel() >= 1, "bad stream_read operands");
+    check_rc(mh_stream_read(buf.data_ptr(), size_t(buf.numel()) * buf.element_size(), sink.data_ptr<float>(), stream_of(buf)),
+             "stream_read");
+}
+
+int64_t version() { return mh_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(magnet, m) {
+    m.def("cspmm(Tensor row_ptr, Tensor col_idx, Tensor val, int n_cols, Tensor X, Tensor(a!) out, float alpha, Tensor? z1, "
+          "float beta1, Tensor? z2, float beta2, Tensor? bias, bool relu, Tensor(b!)? mask, Tensor? plan, int n_long, "
+          "int n_chunks, int chunk, Tensor(c!)? scratch) -> ()");
+    m.def("cspmm_noalloc(Tensor row_ptr, Tensor col_idx, Tensor val, int n_cols, Tensor X, Tensor(a!) out, float alpha, "
+          "Tensor? z1, float beta1, Tensor? z2, float beta2, Tensor? bias, bool relu, Tensor(b!)? mask, Tensor? plan, "
+          "int n_long, int n_chunks, int chunk) -> ()");
+    m.def("plan_build(Tensor row_ptr, int chunk) -> (Tensor, int, int)");
+    m.def("cheb_terms_(Tensor row_ptr, Tensor col_idx, Tensor val, Tensor(a!) Z, Tensor? plan, int n_long, int n_chunks, "
+          "int chunk, Tensor(b!)? scratch) -> ()");
+    m.def("clenshaw(Tensor row_ptr, Tensor col_idx, Tensor val, Tensor Y, Tensor(a!)? work, Tensor(b!) out, Tensor? bias, "
+          "bool relu, Tensor(c!)? mask, Tensor? plan, int n_long, int n_chunks, int chunk, Tensor(d!)? scratch) -> ()");
+    m.def("lap_build(Tensor row, Tensor col, Tensor? weight, int n_nodes, float q, float max_eigen, bool gcn_appr) -> "
+          "(Tensor, Tensor, Tensor, Tensor)");
+    m.def("pack(Tensor real, Tensor imag, Tensor(a!) out) -> ()");
+    m.def("unpack(Tensor p, Tensor(a!) re, Tensor(b!) im) -> ()");
+    m.def("gather_rows(Tensor x, Tensor idx, Tensor(a!) buf) -> ()");
+    m.def("scatter_rows(Tensor buf, Tensor idx, Tensor(a!) x) -> ()");
+    m.def("bias_relu_(Tensor(a!) Y, Tensor? bias, bool relu, Tensor(b!)? mask) -> ()");
+    m.def("relu_bwd_(Tensor(a!) G, Tensor mask) -> ()");
+    m.def("halo_plan(Tensor col_idx, int n_cols, int c0, int c1, Tensor bounds) -> (Tensor, Tensor, Tensor)");
+    m.def("powerlaw_edges(int n_nodes, int seed, int first_edge, Tensor(a!) src, Tensor(b!) dst) -> ()");
+    m.def("stream_read(Tensor buf, Tensor(a!) sink) -> ()");
+    m.def("version() -> int", &version);
+}
+
+TORCH_LIBRARY_IMPL(magnet, CUDA, m) {
+    m.impl("cspmm", &cspmm);
+    m.impl("cspmm_noalloc", &cspmm_noalloc);
+    m.impl("plan_build", &plan_build);
+    m.impl("cheb_terms_", &cheb_terms_);
+    m.impl("clenshaw", &clenshaw);
+    m.impl("lap_build", &lap_build);
+    m.impl("pack", &pack);
+    m.impl("unpack", &unpack);
+    m.impl("gather_rows", &gather_rows);
+    m.impl("scatter_rows", &scatter_rows);
+    m.impl("bias_relu_", &bias_relu_);
+    m.impl("relu_bwd_", &relu_bwd_);
+    m.impl("halo_plan", &halo_plan);
+    m.impl("powerlaw_edges", &powerlaw_edges);
+    m.impl("stream_read", &stream_read);
+}

@@ -1,17 +1,14 @@
-"""Device-resident magnetic Laplacian (complex CSR) and the calls into libmagnet_hip.so
-that build it and apply it.
+"""Device-resident magnetic Laplacian (complex CSR) and the calls that build it and apply it:
+torch.ops.magnet.* of the thin C++ extension, which forwards to the C ABI of libmagnet_hip.so.
 
 `build_magnetic_laplacian` is the GPU counterpart of hermitian_decomp_sparse
 (reference src/utils/hermitian.py:136-168); `MagneticLaplacian.spmm` is one order of the
 propagation (the four torch.spmm of reference src/layer/sparse_magnet.py:9-17 in one pass).
 """
-import ctypes as C
-
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import check, ptr, stream_ptr, require_cuda, MagnetHipError
+from ._lib import ops, require_cuda, MagnetHipError
 
 
 # Optional observer of SpMM launches: set to a callable(start_event, end_event, info) to have every
@@ -41,10 +38,8 @@ def pack_complex(real, imag, out=None):
     n, f = real.shape
     if out is None:
         out = torch.empty((n, 2, f), dtype=torch.float32, device=real.device)
-    ld, im = _packed_strides(out, 'out')
     if n:
-        check(_lib.lib.mh_pack(ptr(real), real.stride(0), ptr(imag), imag.stride(0), ptr(out), ld, im, n, f,
-                               stream_ptr(real.device)))
+        ops.pack(real, imag, out)
     return out
 
 
@@ -52,34 +47,32 @@ def unpack_complex(p):
     """Row-planar [N, 2, F] -> two contiguous planar matrices (mh_unpack); p[:, 0], p[:, 1] are free views
     when strided results are acceptable."""
     require_cuda(p)
-    ld, im = _packed_strides(p, 'p')
+    _packed_strides(p, 'p')
     n, _, f = p.shape
     re = torch.empty((n, f), dtype=torch.float32, device=p.device); imag = torch.empty_like(re)
     if n:
-        check(_lib.lib.mh_unpack(ptr(p), ld, im, ptr(re), f, ptr(imag), f, n, f, stream_ptr(p.device)))
+        ops.unpack(p, re, imag)
     return re, imag
 
 
 def gather_rows(x, idx, out=None):
     """Rows idx of row-planar x into a dense [len(idx), 2, F] buffer (mh_gather_rows): halo send staging."""
     require_cuda(x, idx)
-    ld, im = _packed_strides(x, 'x')
     idx = idx.to(torch.int32).contiguous()
     f = x.size(2)
     if out is None:
         out = torch.empty((idx.numel(), 2, f), dtype=torch.float32, device=x.device)
-    check(_lib.lib.mh_gather_rows(ptr(x), ld, im, ptr(idx), idx.numel(), ptr(out), f, stream_ptr(x.device)))
+    ops.gather_rows(x, idx, out)
     return out
 
 
 def scatter_rows(buf, idx, x):
     """Row i of dense buf [len(idx), 2, F] into row idx[i] of row-planar x (mh_scatter_rows): halo receive."""
     require_cuda(x, idx, buf)
-    ld, im = _packed_strides(x, 'x')
     idx = idx.to(torch.int32).contiguous()
     if not buf.is_contiguous() or buf.size(0) != idx.numel() or buf.size(2) != x.size(2):
         raise MagnetHipError('buf must be contiguous [len(idx), 2, F]')
-    check(_lib.lib.mh_scatter_rows(ptr(buf), ptr(idx), idx.numel(), ptr(x), ld, im, x.size(2), stream_ptr(x.device)))
+    ops.scatter_rows(buf, idx, x)
     return x
 
 
@@ -98,6 +91,7 @@ class MagneticLaplacian:
         self.dinv = dinv
         self._adjoint = None
         self._plan = None
+        self._scratch = {}
 
     # rows longer than 2*PLAN_CHUNK nonzeros are cut into chunks that get a wavefront each
     PLAN_CHUNK = 512
@@ -105,25 +99,27 @@ class MagneticLaplacian:
     def plan(self):
         """(plan tensor or None, n_long, n_chunks, chunk), built on first use (mh_cspmm_plan_*)."""
         if self._plan is None:
-            lib = _lib.lib
             chunk = self.PLAN_CHUNK
-            n_long, n_chunks = C.c_int32(0), C.c_int32(0)
+            self._plan = (None, 0, 0, chunk)
             if self.n_rows > 0 and self.nnz > 2 * chunk:
-                with torch.cuda.device(self.device):
-                    tmp = torch.empty(2, dtype=torch.int32, device=self.device)
-                    s = stream_ptr(self.device)
-                    check(lib.mh_cspmm_plan_count(ptr(self.row_ptr), self.n_rows, chunk, ptr(tmp), C.byref(n_long),
-                                                  C.byref(n_chunks), s))
-                    buf = None
-                    if n_long.value > 0:
-                        buf = torch.empty(lib.mh_cspmm_plan_ints(n_long.value, n_chunks.value), dtype=torch.int32,
-                                          device=self.device)
-                        check(lib.mh_cspmm_plan_fill(ptr(self.row_ptr), self.n_rows, chunk, n_long.value,
-                                                     n_chunks.value, ptr(buf), s))
-                    self._plan = (buf, n_long.value, n_chunks.value, chunk)
-            else:
-                self._plan = (None, 0, 0, chunk)
+                buf, n_long, n_chunks = ops.plan_build(self.row_ptr, chunk)
+                if n_long > 0:
+                    self._plan = (buf, n_long, n_chunks, chunk)
         return self._plan
+
+    def _scratch_for(self, f):
+        """Hub-row partial-sum buffer [n_chunks, 2, F] of this matrix, kept between calls.  One buffer per
+        stream the matrix has been applied on: calls ordered on a stream may share it, calls on different
+        streams may overlap and get their own."""
+        n_chunks = self.plan()[2]
+        if n_chunks == 0:
+            return None
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self._scratch.get(key)
+        need = n_chunks * 2 * f
+        if buf is None or buf.numel() < need:
+            buf = self._scratch[key] = torch.empty(need, dtype=torch.float32, device=self.device)
+        return buf
 
     @property
     def device(self):
@@ -138,52 +134,28 @@ class MagneticLaplacian:
              mask=None):
         """out = alpha * (L X) + beta1 * z1 + beta2 * z2 [+ bias][complex ReLU]; all row-planar [*, 2, F]."""
         require_cuda(X, out, z1, z2, bias, mask)
-        ldx, imx = _packed_strides(X, 'X')
-        if X.size(0) != self.n_cols:
-            raise MagnetHipError('X has %d rows, the Laplacian has %d columns' % (X.size(0), self.n_cols))
+        _packed_strides(X, 'X')
         f = X.size(2)
         if out is None:
             out = torch.empty((self.n_rows, 2, f), dtype=torch.float32, device=X.device)
-        ldy, imy = _packed_strides(out, 'out')
-        if out.size(0) != self.n_rows or out.size(2) != f:
-            raise MagnetHipError('out has shape %s, expected (%d, 2, %d)' % (tuple(out.shape), self.n_rows, f))
-        zargs = []
-        for z, b, name in ((z1, beta1, 'z1'), (z2, beta2, 'z2')):
-            if z is None:
-                zargs += [None, 0, 0, 0.0]
-            else:
-                ldz, imz = _packed_strides(z, name)
-                if z.size(0) != self.n_rows or z.size(2) != f:
-                    raise MagnetHipError('%s has shape %s, expected (%d, 2, %d)' % (name, tuple(z.shape), self.n_rows, f))
-                zargs += [ptr(z), ldz, imz, float(b)]
         if bias is not None:
             bias = bias.reshape(-1).float().contiguous()
-            if bias.numel() != f:
-                raise MagnetHipError('bias has %d entries, expected %d' % (bias.numel(), f))
-        if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != self.n_rows * f or not mask.is_contiguous()):
-            raise MagnetHipError('mask must be contiguous uint8 [n_rows, F]')
         obs = SPMM_OBSERVER
         if obs is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(X.device))
         plan, n_long, n_chunks, chunk = self.plan()
-        scratch = None
-        if n_long > 0:
-            scratch = torch.empty(n_chunks * 2 * f, dtype=torch.float32, device=X.device)
-        check(_lib.lib.mh_cspmm_planned(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), self.n_rows,
-                                        ptr(X), ldx, imx, ptr(out), ldy, imy, float(alpha), *zargs,
-                                        ptr(bias), int(bool(relu)), ptr(mask), f,
-                                        ptr(plan), n_long, n_chunks, chunk, ptr(scratch),
-                                        0 if scratch is None else scratch.numel() * 4, stream_ptr(X.device)))
+        # shapes, dtypes and strides are checked by the extension, which reads (ld, im) off the tensors
+        ops.cspmm(self.row_ptr, self.col_idx, self.val, self.n_cols, X, out, float(alpha), z1, float(beta1), z2, float(beta2),
+                  bias, bool(relu), mask, plan, n_long, n_chunks, chunk, self._scratch_for(f) if n_long > 0 else None)
         if obs is not None:
             ev1.record(torch.cuda.current_stream(X.device))
             obs(ev0, ev1, dict(nnz=self.nnz, n_rows=self.n_rows, F=f, n_addends=int(z1 is not None) + int(z2 is not None)))
         return out
 
-    def _plan_args(self, f, device):
+    def _plan_args(self, f):
         plan, n_long, n_chunks, chunk = self.plan()
-        scratch = torch.empty(n_chunks * 2 * f, dtype=torch.float32, device=device) if n_long > 0 else None
-        return [ptr(plan), n_long, n_chunks, chunk, ptr(scratch), 0 if scratch is None else scratch.numel() * 4]
+        return [plan, n_long, n_chunks, chunk, self._scratch_for(f) if n_long > 0 else None]
 
     def cheb_terms(self, x0, n_terms):
         """[T_0 x0, ..., T_{n_terms-1} x0] as one tensor [n_terms, N, 2, F] (mh_cheb_terms: the whole
@@ -195,8 +167,7 @@ class MagneticLaplacian:
         n, _, f = x0.shape
         z = torch.empty((n_terms, n, 2, f), dtype=torch.float32, device=x0.device)
         z[0].copy_(x0)
-        check(_lib.lib.mh_cheb_terms(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), n, ptr(z), n * 2 * f, n_terms, f,
-                                     *self._plan_args(f, x0.device), stream_ptr(x0.device)))
+        ops.cheb_terms_(self.row_ptr, self.col_idx, self.val, z, *self._plan_args(f))
         return z
 
     def clenshaw(self, y, bias=None, relu=False):
@@ -213,9 +184,7 @@ class MagneticLaplacian:
         mask = torch.empty((n, f), dtype=torch.uint8, device=y.device) if relu else None
         if bias is not None:
             bias = bias.reshape(-1).float().contiguous()
-        check(_lib.lib.mh_clenshaw(ptr(self.row_ptr), ptr(self.col_idx), ptr(self.val), n, ptr(y), n * 2 * f, k1, ptr(work),
-                                   ptr(out), ptr(bias), int(bool(relu)), ptr(mask), f, *self._plan_args(f, y.device),
-                                   stream_ptr(y.device)))
+        ops.clenshaw(self.row_ptr, self.col_idx, self.val, y, work, out, bias, bool(relu), mask, *self._plan_args(f))
         return out, mask
 
     def rows(self, r0, r1):
@@ -312,30 +281,17 @@ def build_magnetic_laplacian(row, col, size, q=0.25, max_eigen=2.0, gcn_appr=Fal
             raise MagnetHipError('edge_weight and row differ in length')
         if w_t.numel() == 0:
             w_t = None                      # no edges: an empty tensor has no data pointer to mark the build weighted
-    n_edges, n = row_t.numel(), int(size)
-    lib = _lib.lib
     with torch.cuda.device(device):
-        ws_bytes = lib.mh_lap_workspace_bytes(n_edges, n, int(w_t is not None), int(bool(gcn_appr)))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        row_ptr = torch.empty(n + 1, dtype=torch.int32, device=device)
-        nnz = C.c_int64(0)
-        s = stream_ptr(device)
-        check(lib.mh_lap_build_count(ptr(row_t), ptr(col_t), int(row_t.dtype == torch.int64), ptr(w_t), n_edges, n,
-                                     float(max_eigen), int(bool(gcn_appr)), ptr(ws), ws_bytes, ptr(row_ptr),
-                                     C.byref(nnz), s))
-        col_idx = torch.empty(nnz.value, dtype=torch.int32, device=device)
-        val = torch.empty((nnz.value, 2), dtype=torch.float32, device=device)
-        dinv = torch.empty(n, dtype=torch.float32, device=device)
-        check(lib.mh_lap_build_fill(n_edges, n, float(q), float(max_eigen), int(w_t is not None), int(bool(gcn_appr)),
-                                    ptr(ws), ws_bytes, nnz.value, ptr(col_idx), ptr(val), ptr(dinv), s))
-        ws.record_stream(torch.cuda.current_stream(device))
-    return MagneticLaplacian(row_ptr, col_idx, val, n, q=q, dinv=dinv)
+        row_ptr, col_idx, val, dinv = ops.lap_build(row_t, col_t, w_t, int(size), float(q), float(max_eigen), bool(gcn_appr))
+    return MagneticLaplacian(row_ptr, col_idx, val, int(size), q=q, dinv=dinv)
 
 
 def powerlaw_edges(n_nodes, n_edges, seed, first_edge=0, device='cuda'):
     """Synthetic power-law digraph on the device (mh_powerlaw_edges): int32 src, dst."""
     src = torch.empty(n_edges, dtype=torch.int32, device=device)
     dst = torch.empty(n_edges, dtype=torch.int32, device=device)
-    check(_lib.lib.mh_powerlaw_edges(int(n_nodes), int(n_edges), int(seed), int(first_edge), ptr(src), ptr(dst),
-                                     stream_ptr(torch.device(device))))
+    if n_edges:
+        ops.powerlaw_edges(int(n_nodes), int(seed), int(first_edge), src, dst)
+    elif n_nodes < 1:
+        raise MagnetHipError('n_nodes must be positive')
     return src, dst

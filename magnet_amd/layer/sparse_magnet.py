@@ -34,8 +34,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib
-from .._lib import check, ptr, stream_ptr, MagnetHipError
+from .._lib import ops, MagnetHipError
 from ..laplacian import MagneticLaplacian, build_magnetic_laplacian, pack_complex, _packed_strides
 from ..utils.hermitian import ChebBasis
 
@@ -142,16 +141,15 @@ def _bias_relu_(p, bias, relu):
     mask = torch.empty((n, f), dtype=torch.uint8, device=p.device) if relu else None
     if bias is None and not relu:
         return None
-    ld, im = _packed_strides(p, 'Y')
     b = None if bias is None else bias.detach().reshape(-1).float().contiguous()
-    check(_lib.lib.mh_bias_relu(ptr(p), ld, im, ptr(b), int(relu), ptr(mask), n, f, stream_ptr(p.device)))
+    if n:
+        ops.bias_relu_(p, b, bool(relu), mask)
     return mask
 
 
 def _relu_bwd_(g, mask):
-    n, _, f = g.shape
-    ld, im = _packed_strides(g, 'G')
-    check(_lib.lib.mh_relu_bwd(ptr(g), ld, im, ptr(mask), n, f, stream_ptr(g.device)))
+    if g.size(0):
+        ops.relu_bwd_(g, mask)
     return g
 
 

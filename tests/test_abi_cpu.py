@@ -22,7 +22,24 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), 'libmagnet_hip.so does not export %s' % n
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib.mh_version() >= 100
+    assert _lib.lib.mh_version() >= 200
+
+
+def test_torch_extension_registers_every_operator():
+    """The product path is torch.ops.magnet.* of libmagnet_torch.so; it has kernels for the GPU dispatch key
+    only, so CPU tensors are refused instead of being computed somewhere else."""
+    import torch
+    from magnet_amd import _lib, MagnetHipError
+    assert os.path.exists(_lib.EXT_PATH)
+    for name in _lib.OPS:
+        assert hasattr(torch.ops.magnet, name), 'torch.ops.magnet.%s is not registered' % name
+    assert _lib.ops.version() == _lib.lib.mh_version() >= 200
+    src = open(os.path.join(ROOT, 'magnet_amd', 'csrc', 'torch_ext.cpp')).read()
+    assert sorted(set(re.findall(r'm\.def\("([a-z_]+)\(', src))) == sorted(_lib.OPS)
+    with pytest.raises(MagnetHipError):
+        _lib.ops.bias_relu_(torch.zeros(3, 2, 4), None, True, None)
+    with pytest.raises(MagnetHipError):
+        _lib.ops.lap_build(torch.zeros(3, dtype=torch.int64), torch.zeros(3, dtype=torch.int64), None, 4, 0.25, 2.0, False)
 
 
 def test_bad_arguments_are_rejected_without_a_device():
