@@ -75,6 +75,30 @@ int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, double max_eig
                       int64_t nnz /* as returned by count */, int32_t* col_idx, float* val /* [nnz][2] */,
                       float* dinv_out /* [n_nodes] or NULL */, void* stream);
 
+/* One rank's ROW BLOCK of the same Laplacian (row-partitioned multi-GPU runs: every rank builds rows
+ * [row_lo, row_hi) only, from the edges incident to them; no counterpart in the single-device reference,
+ * which calls hermitian_decomp_sparse on the whole graph, src/utils/preprocess.py:177-181).
+ * The caller passes the two edge subsets a row block depends on, each in input order:
+ *   fwd: the edges (i, j, w) with i in [row_lo, row_hi)   -> entries (i, j) see w_ij
+ *   bwd: the edges (i, j, w) with j in [row_lo, row_hi)   -> entries (j, i) see w_ij as the reverse weight
+ * (an edge with both endpoints in the block is in both lists; gcn_appr self-loops are appended by the caller).
+ *   mh_lap_block_count -> row_ptr_block[row_hi - row_lo + 1] (0-based inside the block), dinv_block
+ *                         [row_hi - row_lo] = d^-1/2 of the block's rows, nnz of the block (SYNCHRONISES)
+ *   mh_lap_block_fill  -> col_idx (GLOBAL column ids) and val; needs d^-1/2 of EVERY node (dinv_full[n_nodes]:
+ *                         the ranks' dinv_block pieces gathered), because an entry scales with both endpoints.
+ * With row_lo = 0, row_hi = n_nodes and both lists = all edges the result is mh_lap_build_*'s, bit for bit;
+ * the blocks of a partition, stacked, are that CSR.
+ */
+size_t mh_lap_block_workspace_bytes(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int weighted);
+int mh_lap_block_count(const void* fwd_row, const void* fwd_col, const float* fwd_w, int64_t n_fwd,
+                       const void* bwd_row, const void* bwd_col, const float* bwd_w, int64_t n_bwd, int idx64,
+                       int weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
+                       void* workspace, size_t workspace_bytes, int32_t* row_ptr_block, float* dinv_block,
+                       int64_t* nnz_host, void* stream);
+int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double q,
+                      double max_eigen, int weighted, void* workspace, size_t workspace_bytes, int64_t nnz,
+                      const float* dinv_full, int32_t* col_idx, float* val, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fused complex CSR SpMM, one Chebyshev order.
  * Replaces the four torch.spmm of process()  — src/layer/sparse_magnet.py:9-17 —

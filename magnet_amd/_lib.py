@@ -39,6 +39,13 @@ def _load():
                                        C.POINTER(i64), vp]
     lib.mh_lap_build_fill.restype = C.c_int
     lib.mh_lap_build_fill.argtypes = [i64, i32, f64, f64, C.c_int, C.c_int, vp, sz, i64, vp, vp, vp, vp]
+    lib.mh_lap_block_workspace_bytes.restype = sz
+    lib.mh_lap_block_workspace_bytes.argtypes = [i64, i64, i32, C.c_int]
+    lib.mh_lap_block_count.restype = C.c_int
+    lib.mh_lap_block_count.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, C.c_int, C.c_int, i32, i32, i32, f64, vp, sz, vp, vp,
+                                       C.POINTER(i64), vp]
+    lib.mh_lap_block_fill.restype = C.c_int
+    lib.mh_lap_block_fill.argtypes = [i64, i64, i32, i32, i32, f64, f64, C.c_int, vp, sz, i64, vp, vp, vp, vp]
     lib.mh_cspmm.restype = C.c_int
     lib.mh_cspmm.argtypes = [vp, vp, vp, i32,
                              vp, i64, i64,
@@ -88,7 +95,8 @@ def _load():
 lib = _load()
 
 # operators the extension registers (csrc/torch_ext.cpp)
-OPS = ['cspmm', 'cspmm_noalloc', 'plan_build', 'cheb_terms_', 'clenshaw', 'lap_build', 'pack', 'unpack',
+OPS = ['cspmm', 'cspmm_noalloc', 'plan_build', 'cheb_terms_', 'clenshaw', 'lap_build', 'lap_block_count',
+       'lap_block_fill', 'pack', 'unpack',
        'gather_rows', 'scatter_rows', 'bias_relu_', 'relu_bwd_', 'halo_plan', 'powerlaw_edges', 'stream_read',
        'version']
 
@@ -124,6 +132,7 @@ ops = _Ops()
 EXPORTS = [
     'mh_version', 'mh_last_error',
     'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
+    'mh_lap_block_workspace_bytes', 'mh_lap_block_count', 'mh_lap_block_fill',
     'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
     'mh_cheb_terms', 'mh_clenshaw',
     'mh_halo_plan_workspace_bytes', 'mh_halo_plan_count', 'mh_halo_plan_fill',

@@ -38,20 +38,21 @@ using mhscan::scan_tile_sums;
 using mhscan::scan_tiles;
 using mhscan::scan_tile_write;
 
+constexpr int kLongRun = 64;          // (row, col) runs longer than this are summed by a whole wavefront
+
 struct Header {          // first 256 bytes of the workspace
-    int32_t err;         // != 0: an endpoint was out of range
-    int32_t pad;
+    int32_t err;         // bit 0: an endpoint outside [0, n_nodes); bit 1: a record outside the row block
+    int32_t n_long;      // number of (row, col) runs longer than kLongRun records
     int64_t kept;        // number of kept off-diagonal entries
 };
 
 struct Layout {
-    int64_t e_total;     // edges incl. gcn self-loops
-    int64_t m;           // directed records = 2 * e_total
+    int64_t m;           // directed records
     int64_t m_pad;       // m rounded up to the scan tile
     int64_t n_tiles;
     int cb;              // bits per node id
     size_t off_hdr, off_keys0, off_keys1, off_w0, off_w1, off_flags, off_pos, off_recptr, off_dinv,
-        off_tiles, off_sort, sort_bytes, total;
+        off_tiles, off_long, off_sort, sort_bytes, total;
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -62,10 +63,10 @@ int node_bits(int32_t n_nodes) {
     return cb;
 }
 
-Layout make_layout(int64_t n_edges, int32_t n_nodes, bool weighted, bool gcn) {
+// workspace for m directed records over n_nodes nodes
+Layout make_layout(int64_t m, int32_t n_nodes, bool weighted) {
     Layout L{};
-    L.e_total = n_edges + (gcn ? int64_t(n_nodes) : 0);
-    L.m = 2 * L.e_total;
+    L.m = m;
     L.n_tiles = L.m / kScanTile + 1;              // covers positions 0..m (pos[m] = total)
     L.m_pad = L.n_tiles * kScanTile;
     L.cb = node_bits(n_nodes);
@@ -80,6 +81,7 @@ Layout make_layout(int64_t n_edges, int32_t n_nodes, bool weighted, bool gcn) {
     L.off_recptr = o;   o += align_up(size_t(n_nodes + 1) * 4);
     L.off_dinv = o;     o += align_up(size_t(n_nodes) * 4 + 4);
     L.off_tiles = o;    o += align_up(size_t(L.n_tiles + 1) * 4);
+    L.off_long = o;     o += align_up(size_t(L.m / (kLongRun + 1) + 1) * 4);
     L.off_sort = o;
     L.sort_bytes = mhsort::workspace_bytes(L.m > 0 ? L.m : 1);
     o += align_up(L.sort_bytes);
@@ -87,45 +89,57 @@ Layout make_layout(int64_t n_edges, int32_t n_nodes, bool weighted, bool gcn) {
     return L;
 }
 
-// ---------------------------------------------------------------------------
-// 1. records
-// ---------------------------------------------------------------------------
-template <typename IdxT>
-__global__ void __launch_bounds__(kBlock) make_records(const IdxT* __restrict__ row, const IdxT* __restrict__ col,
-                                                      const float* __restrict__ weight, int64_t n_edges,
-                                                      int64_t e_total, int32_t n_nodes, int cb,
-                                                      uint64_t* __restrict__ keys, float* __restrict__ w_out,
-                                                      Header* hdr) {
-    int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (e >= e_total) return;
-    int64_t i, j;
-    float w = 1.0f;
-    if (e < n_edges) {
-        i = int64_t(row[e]); j = int64_t(col[e]);
-        if (weight) w = weight[e];
-    } else {                       // gcn_appr self-loop of weight 1 (hermitian.py:144-145)
-        i = j = e - n_edges;
-    }
-    if (i < 0 || j < 0 || i >= n_nodes || j >= n_nodes) {
-        atomicOr(&hdr->err, 1);    // flag only; the record is made harmless below
-        i = j = 0; w = 0.0f;
-    }
-    uint64_t ui = uint64_t(i), uj = uint64_t(j);
-    keys[e] = (ui << (cb + 1)) | (uj << 1);
-    keys[e_total + e] = (uj << (cb + 1)) | (ui << 1) | 1ull;
-    if (w_out) { w_out[e] = w; w_out[e_total + e] = w; }
+inline int64_t full_records(int64_t n_edges, int32_t n_nodes, bool gcn) {
+    return 2 * (n_edges + (gcn ? int64_t(n_nodes) : 0));
 }
 
 // ---------------------------------------------------------------------------
-// 3a. first record of every row: rec_ptr[r] = first p with row(p) >= r ; rec_ptr[n] = m
+// 1. records of ONE direction: edge e = (i, j, w) of the list, or the self-loop (e - n_in, e - n_in, 1) for
+// n_in <= e < n_in + n_self (gcn_appr, hermitian.py:144-145), becomes the forward record (i, j, dir 0) or,
+// with swap, the backward record (j, i, dir 1).  A record's row must lie in [row_lo, row_hi).
+// ---------------------------------------------------------------------------
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock) make_records(const IdxT* __restrict__ row, const IdxT* __restrict__ col,
+                                                      const float* __restrict__ weight, int64_t n_in, int64_t n_self,
+                                                      int swap, int32_t n_nodes, int32_t row_lo, int32_t row_hi, int cb,
+                                                      uint64_t* __restrict__ keys, float* __restrict__ w_out,
+                                                      Header* hdr) {
+    int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= n_in + n_self) return;
+    int64_t i, j;
+    float w = 1.0f;
+    if (e < n_in) {
+        i = int64_t(row[e]); j = int64_t(col[e]);
+        if (weight) w = weight[e];
+    } else {
+        i = j = e - n_in;
+    }
+    if (i < 0 || j < 0 || i >= n_nodes || j >= n_nodes) {
+        atomicOr(&hdr->err, 1);    // flag only; the record is made harmless below
+        i = j = row_lo; w = 0.0f;
+    }
+    const int64_t r = swap ? j : i, c = swap ? i : j;
+    if (r < row_lo || r >= row_hi) atomicOr(&hdr->err, 2);
+    keys[e] = (uint64_t(r) << (cb + 1)) | (uint64_t(c) << 1) | (swap ? 1ull : 0ull);
+    if (w_out) w_out[e] = w;
+}
+
+// ---------------------------------------------------------------------------
+// 3a. first record of every row: rec_ptr[r] = first p with row(p) >= r ; rec_ptr[n] = m.  One binary search
+// per row (neighbouring rows end next to each other, so a wave's searches share their cache lines); cost
+// does not depend on how the records are spread over the rows.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) row_starts(const uint64_t* __restrict__ keys, int64_t m, int32_t n_nodes,
                                                      int cb, int32_t* __restrict__ rec_ptr) {
-    int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (p > m) return;
-    int64_t r_cur = (p < m) ? int64_t(keys[p] >> (cb + 1)) : int64_t(n_nodes);
-    int64_t r_prev = (p > 0) ? int64_t(keys[p - 1] >> (cb + 1)) : -1;
-    for (int64_t r = r_prev + 1; r <= r_cur; ++r) rec_ptr[r] = int32_t(p);
+    int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (r > n_nodes) return;
+    const uint64_t target = uint64_t(r) << (cb + 1);
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    rec_ptr[r] = int32_t(lo);
 }
 
 // ---------------------------------------------------------------------------
@@ -162,12 +176,21 @@ __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_counts(const int32_t* 
 // ---------------------------------------------------------------------------
 // 3b. (row, col) segments.  The thread on a segment's first record walks the segment:
 // forward records come first (they precede the backward ones in the input and the sort is stable;
-// dir is the key's lowest bit), each side is summed in fp32 in
-// stored (= input) order.
+// dir is the key's lowest bit), each side is summed in fp32 in stored (= input) order.
+// A run longer than kLongRun records (the same directed pair listed hundreds of times) is not walked
+// by one thread: its head is put on a list and a whole wavefront sums it (segments_long).
 // ---------------------------------------------------------------------------
+__device__ inline uint8_t finish_segment(float fwd, float bwd, int64_t p, float* seg_s, float* seg_d) {
+    float s = 0.5f * (fwd + bwd);                  // hermitian.py:147
+    float d = fwd - bwd;                           // hermitian.py:157
+    seg_s[p] = s; seg_d[p] = d;
+    return (d != 0.0f && s != 0.0f) ? 1 : 0;       // exact zeros are not stored by the CSR binops
+}
+
 __global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
                                                    int64_t m, float* __restrict__ seg_s, float* __restrict__ seg_d,
-                                                   uint8_t* __restrict__ flags) {
+                                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_list,
+                                                   Header* hdr) {
     int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= m) return;
     uint64_t k = keys[p];
@@ -178,27 +201,68 @@ __global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ 
         float fwd = 0.0f, bwd = 0.0f;
         int64_t t = p;
         uint64_t kt = k;
-        while (true) {
+        bool ended = false;
+        for (int step = 0; step < kLongRun; ++step) {
             float w = w_sorted ? w_sorted[t] : 1.0f;
             if (kt & 1ull) bwd += w; else fwd += w;
             ++t;
-            if (t >= m) break;
+            if (t >= m) { ended = true; break; }
             kt = keys[t];
-            if ((kt >> 1) != pair) break;
+            if ((kt >> 1) != pair) { ended = true; break; }
         }
-        float s = 0.5f * (fwd + bwd);                  // hermitian.py:147
-        float d = fwd - bwd;                           // hermitian.py:157
-        seg_s[p] = s; seg_d[p] = d;
-        keep = (d != 0.0f && s != 0.0f) ? 1 : 0;       // exact zeros are not stored by the CSR binops
+        if (ended) keep = finish_segment(fwd, bwd, p, seg_s, seg_d);
+        else long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag written by segments_long
     }
     flags[p] = keep;
 }
 
+// One wavefront per long run, 64 records per step: the lanes load the step's records side by side (coalesced),
+// then the weights are added in stored order, the same fp32 sequence the single-thread walk of a short run
+// performs (every lane carries the same running sums), at one shuffle + add per record instead of one
+// dependent memory access per record.  Unweighted runs are counted.
+// The grid is fixed; the waves stride over the list whose length the kernel before left in the header.
+__global__ void __launch_bounds__(kBlock) segments_long(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
+                                                        int64_t m, float* __restrict__ seg_s, float* __restrict__ seg_d,
+                                                        uint8_t* __restrict__ flags, const uint32_t* __restrict__ long_list,
+                                                        const Header* hdr) {
+    const int lane = threadIdx.x & 63;
+    const int n_long = hdr->n_long;
+    const int n_waves = int(gridDim.x) * (kBlock / 64);
+    for (int li = int(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6); li < n_long; li += n_waves) {
+        const int64_t p = int64_t(long_list[li]);
+        const uint64_t pair = keys[p] >> 1;
+        float fwd = 0.0f, bwd = 0.0f;
+        for (int64_t base = p;; base += 64) {
+            const int64_t t = base + lane;
+            uint64_t kt = 0;
+            bool in_run = false;
+            float w = 1.0f;
+            if (t < m) { kt = keys[t]; in_run = (kt >> 1) == pair; }
+            if (in_run && w_sorted) w = w_sorted[t];
+            const uint64_t run_mask = __ballot(in_run);                   // a prefix of the lanes: the records are sorted
+            const uint64_t bwd_mask = __ballot(in_run && (kt & 1ull));
+            const int cnt = __popcll(run_mask);
+            if (w_sorted) {
+                for (int j = 0; j < cnt; ++j) {
+                    const float wj = __shfl(w, j, 64);
+                    if ((bwd_mask >> j) & 1ull) bwd += wj; else fwd += wj;
+                }
+            } else {
+                fwd += float(__popcll(run_mask & ~bwd_mask));
+                bwd += float(__popcll(bwd_mask));
+            }
+            if (cnt < 64) break;                                          // the run ended inside these 64 records
+        }
+        if (lane == 0) flags[p] = finish_segment(fwd, bwd, p, seg_s, seg_d);
+    }
+}
+
+// row_ptr of the rows [row_lo, row_hi]: CSR slot of the row's first kept entry (+ one diagonal per earlier row)
 __global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restrict__ rec_ptr, const uint32_t* __restrict__ pos,
-                                                        int32_t n_nodes, int diag, int32_t* __restrict__ row_ptr) {
-    int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (r > n_nodes) return;
-    row_ptr[r] = int32_t(pos[rec_ptr[r]]) + (diag ? int32_t(r) : 0);
+                                                        int32_t row_lo, int32_t row_hi, int diag, int32_t* __restrict__ row_ptr) {
+    int64_t r = int64_t(row_lo) + int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (r > row_hi) return;
+    row_ptr[r - row_lo] = int32_t(pos[rec_ptr[r]]) + (diag ? int32_t(r - row_lo) : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -207,7 +271,7 @@ __global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restric
 __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ flags,
                                                        const uint32_t* __restrict__ pos, const float* __restrict__ seg_s,
                                                        const float* __restrict__ seg_d, const float* __restrict__ dinv,
-                                                       int64_t m, int cb, float two_pi_q, float scale, int diag,
+                                                       int64_t m, int cb, int32_t row_lo, float two_pi_q, float scale, int diag,
                                                        int64_t nnz, int32_t* __restrict__ col_idx,
                                                        float2* __restrict__ val) {
     int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
@@ -216,7 +280,7 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
     int32_t r = int32_t(k >> (cb + 1));
     int32_t c = int32_t((k >> 1) & ((1ull << cb) - 1ull));
     int64_t idx = int64_t(pos[p]);
-    if (diag) idx += int64_t(r) + (c > r ? 1 : 0);
+    if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
     if (idx >= nnz) return;                            // caller's arrays are shorter than the count phase reported
     float a = (dinv[r] * seg_s[p]) * dinv[c];          // (D A_s) D, hermitian.py:154
     float theta = two_pi_q * seg_d[p];                 // fp32 product, hermitian.py:157
@@ -227,19 +291,19 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
     val[idx] = make_float2(re * scale, im * scale);    // (2/lmax) L - I, hermitian.py:167
 }
 
-// diagonal (2/lmax - 1) of every row; its slot follows the row's kept entries with col < r
+// diagonal (2/lmax - 1) of every row of the block; its slot follows the row's kept entries with col < r
 __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
-                                                        int64_t m, int32_t n_nodes, int cb, float diag_val, int64_t nnz,
-                                                        int32_t* __restrict__ col_idx, float2* __restrict__ val) {
-    int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (r >= n_nodes) return;
+                                                        int64_t m, int32_t row_lo, int32_t row_hi, int cb, float diag_val,
+                                                        int64_t nnz, int32_t* __restrict__ col_idx, float2* __restrict__ val) {
+    int64_t r = int64_t(row_lo) + int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= row_hi) return;
     uint64_t target = (uint64_t(r) << (cb + 1)) | (uint64_t(r) << 1);
     int64_t lo = 0, hi = m;                             // lower_bound(keys, target)
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
         if (keys[mid] < target) lo = mid + 1; else hi = mid;
     }
-    int64_t idx = int64_t(pos[lo]) + r;
+    int64_t idx = int64_t(pos[lo]) + (r - row_lo);
     if (idx >= nnz) return;
     col_idx[idx] = int32_t(r);
     val[idx] = make_float2(diag_val, 0.0f);
@@ -247,11 +311,146 @@ __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restri
 
 inline unsigned grid_for(int64_t n) { return unsigned((n + kBlock - 1) / kBlock); }
 
+struct Work {            // the workspace cut up
+    Header* hdr; uint64_t *keys0, *keys1; float *w0, *w1; uint8_t* flags; uint32_t* pos; int32_t* rec_ptr; float* dinv;
+    uint32_t* tiles; uint32_t* long_list; char* sort;
+};
+
+Work cut(void* workspace, const Layout& L, bool weighted) {
+    char* ws = static_cast<char*>(workspace);
+    Work w{};
+    w.hdr = reinterpret_cast<Header*>(ws + L.off_hdr);
+    w.keys0 = reinterpret_cast<uint64_t*>(ws + L.off_keys0);
+    w.keys1 = reinterpret_cast<uint64_t*>(ws + L.off_keys1);
+    w.w0 = weighted ? reinterpret_cast<float*>(ws + L.off_w0) : nullptr;
+    w.w1 = weighted ? reinterpret_cast<float*>(ws + L.off_w1) : nullptr;
+    w.flags = reinterpret_cast<uint8_t*>(ws + L.off_flags);
+    w.pos = reinterpret_cast<uint32_t*>(ws + L.off_pos);
+    w.rec_ptr = reinterpret_cast<int32_t*>(ws + L.off_recptr);
+    w.dinv = reinterpret_cast<float*>(ws + L.off_dinv);
+    w.tiles = reinterpret_cast<uint32_t*>(ws + L.off_tiles);
+    w.long_list = reinterpret_cast<uint32_t*>(ws + L.off_long);
+    w.sort = ws + L.off_sort;
+    return w;
+}
+
+struct EdgeList { const void* row; const void* col; const float* w; int64_t n; int64_t n_self; };
+
+// The sort key is (row, col) = key bits [1, 2cb+1).  The direction bit 0 is NOT sorted: all forward
+// records are written before all backward records and the sort is stable, so inside a (row, col)
+// segment the forward records still come first, each side in input order.
+// An odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1,
+// so that the sorted records always end in keys1 / w1.
+int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const EdgeList& bwd, int idx64, bool weighted,
+                     int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream) {
+    const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
+    uint64_t* rec_keys = start_in_0 ? W.keys0 : W.keys1;
+    float* rec_w = weighted ? (start_in_0 ? W.w0 : W.w1) : nullptr;
+    const EdgeList* lists[2] = {&fwd, &bwd};
+    int64_t at = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+        const EdgeList& e = *lists[dir];
+        const int64_t cnt = e.n + e.n_self;
+        if (cnt == 0) continue;
+        if (idx64)
+            make_records<int64_t><<<grid_for(cnt), kBlock, 0, stream>>>(
+                static_cast<const int64_t*>(e.row), static_cast<const int64_t*>(e.col), e.w, e.n, e.n_self, dir, n_nodes,
+                row_lo, row_hi, L.cb, rec_keys + at, rec_w ? rec_w + at : nullptr, W.hdr);
+        else
+            make_records<int32_t><<<grid_for(cnt), kBlock, 0, stream>>>(
+                static_cast<const int32_t*>(e.row), static_cast<const int32_t*>(e.col), e.w, e.n, e.n_self, dir, n_nodes,
+                row_lo, row_hi, L.cb, rec_keys + at, rec_w ? rec_w + at : nullptr, W.hdr);
+        MH_LAUNCH_CHECK("make_records");
+        at += cnt;
+    }
+    if (L.m > 0) {
+        uint64_t* other = rec_keys == W.keys0 ? W.keys1 : W.keys0;
+        float* other_w = weighted ? (rec_w == W.w0 ? W.w1 : W.w0) : nullptr;
+        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, W.sort, L.sort_bytes, stream));
+    }
+    return MH_OK;
+}
+
+// everything of the count phase after the sort; rows [row_lo, row_hi) are the rows the records belong to
+int count_sorted(const Layout& L, const Work& W, bool weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, int diag,
+                 int32_t* row_ptr, float* dinv_block, int64_t* nnz_host, hipStream_t stream) {
+    row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb, W.rec_ptr);
+    MH_LAUNCH_CHECK("row_starts");
+    if (n_nodes > 0) {
+        if (weighted)
+            degree_inv_sqrt_weighted<<<grid_for(int64_t(n_nodes) * 64), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
+        else
+            degree_inv_sqrt_counts<<<grid_for(n_nodes), kBlock, 0, stream>>>(W.rec_ptr, n_nodes, W.dinv);
+        MH_LAUNCH_CHECK("degree_inv_sqrt");
+    }
+    float* seg_s = reinterpret_cast<float*>(W.keys0);           // keys0 is free after the sort
+    float* seg_d = seg_s + L.m_pad;
+    if (L.m > 0) {
+        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.flags, W.long_list, W.hdr);
+        MH_LAUNCH_CHECK("segments");
+        segments_long<<<1024, kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.flags, W.long_list, W.hdr);
+        MH_LAUNCH_CHECK("segments_long");
+    }
+    scan_tile_sums<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.flags, W.tiles);
+    MH_LAUNCH_CHECK("scan_tile_sums");
+    scan_tiles<<<1, 1024, 0, stream>>>(W.tiles, L.n_tiles, &W.hdr->kept);
+    MH_LAUNCH_CHECK("scan_tiles");
+    scan_tile_write<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.flags, W.tiles, W.pos, L.m);
+    MH_LAUNCH_CHECK("scan_tile_write");
+    write_row_ptr<<<grid_for(int64_t(row_hi - row_lo) + 1), kBlock, 0, stream>>>(W.rec_ptr, W.pos, row_lo, row_hi, diag, row_ptr);
+    MH_LAUNCH_CHECK("write_row_ptr");
+    if (dinv_block && row_hi > row_lo)
+        MH_HIP(hipMemcpyAsync(dinv_block, W.dinv + row_lo, size_t(row_hi - row_lo) * 4, hipMemcpyDeviceToDevice, stream));
+    Header h{};
+    MH_HIP(hipMemcpyAsync(&h, W.hdr, sizeof(Header), hipMemcpyDeviceToHost, stream));
+    MH_HIP(hipStreamSynchronize(stream));
+    if (h.err & 1) return mh::fail(MH_ERR_INDEX, "an edge endpoint is outside [0, %d)", n_nodes);
+    if (h.err & 2) return mh::fail(MH_ERR_INDEX, "an edge does not belong to the row block [%d, %d)", row_lo, row_hi);
+    *nnz_host = h.kept + (diag ? int64_t(row_hi - row_lo) : 0);
+    return MH_OK;
+}
+
+int fill_sorted(const Layout& L, const Work& W, int32_t row_lo, int32_t row_hi, double q, double max_eigen, int64_t nnz,
+                const float* dinv, int32_t* col_idx, float* val, hipStream_t stream) {
+    const float* seg_s = reinterpret_cast<const float*>(W.keys0);
+    const float* seg_d = seg_s + L.m_pad;
+    const float scale = float(2.0 / max_eigen);                 // the double quotient rounded once (hermitian.py:167)
+    const float diag_val = scale * 1.0f - 1.0f;
+    const int diag = diag_val != 0.0f;
+    // 2*pi*q as the reference forms it: a double product rounded to fp32 when it meets the
+    // float32 matrix (complex64 scalar), hermitian.py:157
+    const float two_pi_q = float(2.0 * 3.14159265358979323846 * q);
+    if (L.m > 0 && nnz > 0) {
+        MH_REQUIRE(col_idx && val, "col_idx/val is null");
+        MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
+        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.flags, W.pos, seg_s, seg_d, dinv, L.m, L.cb, row_lo,
+                                                           two_pi_q, scale, diag, nnz, col_idx, reinterpret_cast<float2*>(val));
+        MH_LAUNCH_CHECK("emit_entries");
+    }
+    if (diag && row_hi > row_lo) {
+        MH_REQUIRE(col_idx && val && nnz >= row_hi - row_lo, "col_idx/val is null or nnz too small for the diagonal");
+        emit_diagonal<<<grid_for(row_hi - row_lo), kBlock, 0, stream>>>(W.keys1, W.pos, L.m, row_lo, row_hi, L.cb, diag_val, nnz,
+                                                                        col_idx, reinterpret_cast<float2*>(val));
+        MH_LAUNCH_CHECK("emit_diagonal");
+    }
+    return MH_OK;
+}
+
+int prepare(const Layout& L, void* workspace, size_t workspace_bytes, const Work& W, int64_t n_rows_out, hipStream_t stream) {
+    if (L.m >= (int64_t(1) << 31) - 1 - n_rows_out) return mh::fail(MH_ERR_RANGE, "2*edges does not fit int32 CSR indices");
+    if (workspace_bytes < L.total)
+        return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
+    MH_REQUIRE(mh_aligned16(workspace), "workspace must be 16-byte aligned");
+    MH_HIP(hipMemsetAsync(W.hdr, 0, 256, stream));
+    MH_HIP(hipMemsetAsync(W.flags, 0, size_t(L.m_pad), stream));
+    return MH_OK;
+}
+
 }  // namespace
 
 extern "C" size_t mh_lap_workspace_bytes(int64_t n_edges, int32_t n_nodes, int weighted, int gcn_appr) {
     if (n_edges < 0 || n_nodes < 0) return 0;
-    return make_layout(n_edges, n_nodes, weighted != 0, gcn_appr != 0).total;
+    return make_layout(full_records(n_edges, n_nodes, gcn_appr != 0), n_nodes, weighted != 0).total;
 }
 
 extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, const float* weight,
@@ -264,78 +463,15 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
     MH_REQUIRE(workspace && row_ptr && nnz_host, "workspace/row_ptr/nnz_host is null");
     MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
     const bool weighted = weight != nullptr, gcn = gcn_appr != 0;
-    Layout L = make_layout(n_edges, n_nodes, weighted, gcn);
-    if (L.m >= (int64_t(1) << 31) - 1 - n_nodes) return mh::fail(MH_ERR_RANGE, "2*edges does not fit int32 CSR indices");
-    if (workspace_bytes < L.total)
-        return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
-    MH_REQUIRE(mh_aligned16(workspace), "workspace must be 16-byte aligned");
-    char* ws = static_cast<char*>(workspace);
-    Header* hdr = reinterpret_cast<Header*>(ws + L.off_hdr);
-    uint64_t* keys0 = reinterpret_cast<uint64_t*>(ws + L.off_keys0);
-    uint64_t* keys1 = reinterpret_cast<uint64_t*>(ws + L.off_keys1);
-    float* w0 = weighted ? reinterpret_cast<float*>(ws + L.off_w0) : nullptr;
-    float* w1 = weighted ? reinterpret_cast<float*>(ws + L.off_w1) : nullptr;
-    uint8_t* flags = reinterpret_cast<uint8_t*>(ws + L.off_flags);
-    uint32_t* pos = reinterpret_cast<uint32_t*>(ws + L.off_pos);
-    int32_t* rec_ptr = reinterpret_cast<int32_t*>(ws + L.off_recptr);
-    float* dinv = reinterpret_cast<float*>(ws + L.off_dinv);
-    uint32_t* tiles = reinterpret_cast<uint32_t*>(ws + L.off_tiles);
-    const float scale = float(2.0 / max_eigen);                 // the double quotient rounded once (hermitian.py:167)
-    const int diag = (scale * 1.0f - 1.0f) != 0.0f;
-
-    MH_HIP(hipMemsetAsync(hdr, 0, 256, stream));
-    MH_HIP(hipMemsetAsync(flags, 0, size_t(L.m_pad), stream));
-    // The sort key is (row, col) = key bits [1, 2cb+1).  The direction bit 0 is NOT sorted: all forward
-    // records are written before all backward records and the sort is stable, so inside a (row, col)
-    // segment the forward records still come first, each side in input order.
-    // An odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1.
-    const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
-    uint64_t* rec_keys = start_in_0 ? keys0 : keys1;
-    float* rec_w = weighted ? (start_in_0 ? w0 : w1) : nullptr;
-    if (L.e_total > 0) {
-        if (idx64)
-            make_records<int64_t><<<grid_for(L.e_total), kBlock, 0, stream>>>(
-                static_cast<const int64_t*>(row), static_cast<const int64_t*>(col), weight, n_edges, L.e_total,
-                n_nodes, L.cb, rec_keys, rec_w, hdr);
-        else
-            make_records<int32_t><<<grid_for(L.e_total), kBlock, 0, stream>>>(
-                static_cast<const int32_t*>(row), static_cast<const int32_t*>(col), weight, n_edges, L.e_total,
-                n_nodes, L.cb, rec_keys, rec_w, hdr);
-        MH_LAUNCH_CHECK("make_records");
-        // passes alternate between the two buffers; the records were written so that the result lands in keys1
-        uint64_t* other = rec_keys == keys0 ? keys1 : keys0;
-        float* other_w = weighted ? (rec_w == w0 ? w1 : w0) : nullptr;
-        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, ws + L.off_sort, L.sort_bytes, stream));
-    }
-    row_starts<<<grid_for(L.m + 1), kBlock, 0, stream>>>(keys1, L.m, n_nodes, L.cb, rec_ptr);
-    MH_LAUNCH_CHECK("row_starts");
-    if (n_nodes > 0) {
-        if (weighted)
-            degree_inv_sqrt_weighted<<<grid_for(int64_t(n_nodes) * 64), kBlock, 0, stream>>>(rec_ptr, w1, n_nodes, dinv);
-        else
-            degree_inv_sqrt_counts<<<grid_for(n_nodes), kBlock, 0, stream>>>(rec_ptr, n_nodes, dinv);
-        MH_LAUNCH_CHECK("degree_inv_sqrt");
-    }
-    float* seg_s = reinterpret_cast<float*>(keys0);             // keys0 is free after the sort
-    float* seg_d = seg_s + L.m_pad;
-    if (L.m > 0) {
-        segments<<<grid_for(L.m), kBlock, 0, stream>>>(keys1, w1, L.m, seg_s, seg_d, flags);
-        MH_LAUNCH_CHECK("segments");
-    }
-    scan_tile_sums<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(flags, tiles);
-    MH_LAUNCH_CHECK("scan_tile_sums");
-    scan_tiles<<<1, 1024, 0, stream>>>(tiles, L.n_tiles, &hdr->kept);
-    MH_LAUNCH_CHECK("scan_tiles");
-    scan_tile_write<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(flags, tiles, pos, L.m);
-    MH_LAUNCH_CHECK("scan_tile_write");
-    write_row_ptr<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(rec_ptr, pos, n_nodes, diag, row_ptr);
-    MH_LAUNCH_CHECK("write_row_ptr");
-    Header h{};
-    MH_HIP(hipMemcpyAsync(&h, hdr, sizeof(Header), hipMemcpyDeviceToHost, stream));
-    MH_HIP(hipStreamSynchronize(stream));
-    if (h.err) return mh::fail(MH_ERR_INDEX, "an edge endpoint is outside [0, %d)", n_nodes);
-    *nnz_host = h.kept + (diag ? int64_t(n_nodes) : 0);
-    return MH_OK;
+    Layout L = make_layout(full_records(n_edges, n_nodes, gcn), n_nodes, weighted);
+    Work W = cut(workspace, L, weighted);
+    int rc = prepare(L, workspace, workspace_bytes, W, n_nodes, stream);
+    if (rc != MH_OK) return rc;
+    const int diag = (float(2.0 / max_eigen) * 1.0f - 1.0f) != 0.0f;
+    EdgeList e{row, col, weight, n_edges, gcn ? int64_t(n_nodes) : 0};
+    rc = records_and_sort(L, W, e, e, idx64, weighted, n_nodes, 0, n_nodes, stream);
+    if (rc != MH_OK) return rc;
+    return count_sorted(L, W, weighted, n_nodes, 0, n_nodes, diag, row_ptr, nullptr, nnz_host, stream);
 }
 
 extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, double max_eigen, int weighted_,
@@ -345,37 +481,60 @@ extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, dou
     MH_REQUIRE(nnz >= 0, "negative nnz");
     MH_REQUIRE(n_edges >= 0 && n_nodes >= 0 && workspace, "bad size or null workspace");
     MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
-    const bool weighted = weighted_ != 0, gcn = gcn_appr != 0;
-    Layout L = make_layout(n_edges, n_nodes, weighted, gcn);
+    const bool weighted = weighted_ != 0;
+    Layout L = make_layout(full_records(n_edges, n_nodes, gcn_appr != 0), n_nodes, weighted);
     if (workspace_bytes < L.total)
         return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
-    char* ws = static_cast<char*>(workspace);
-    const uint64_t* keys1 = reinterpret_cast<const uint64_t*>(ws + L.off_keys1);
-    const uint8_t* flags = reinterpret_cast<const uint8_t*>(ws + L.off_flags);
-    const uint32_t* pos = reinterpret_cast<const uint32_t*>(ws + L.off_pos);
-    const float* dinv = reinterpret_cast<const float*>(ws + L.off_dinv);
-    const float* seg_s = reinterpret_cast<const float*>(ws + L.off_keys0);
-    const float* seg_d = seg_s + L.m_pad;
-    const float scale = float(2.0 / max_eigen);
-    const float diag_val = scale * 1.0f - 1.0f;
-    const int diag = diag_val != 0.0f;
-    // 2*pi*q as the reference forms it: a double product rounded to fp32 when it meets the
-    // float32 matrix (complex64 scalar), hermitian.py:157
-    const float two_pi_q = float(2.0 * 3.14159265358979323846 * q);
-    if (L.m > 0 && nnz > 0) {
-        MH_REQUIRE(col_idx && val, "col_idx/val is null");
-        MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
-        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(keys1, flags, pos, seg_s, seg_d, dinv, L.m, L.cb, two_pi_q,
-                                                           scale, diag, nnz, col_idx, reinterpret_cast<float2*>(val));
-        MH_LAUNCH_CHECK("emit_entries");
-    }
-    if (diag && n_nodes > 0) {
-        MH_REQUIRE(col_idx && val && nnz >= n_nodes, "col_idx/val is null or nnz too small for the diagonal");
-        emit_diagonal<<<grid_for(n_nodes), kBlock, 0, stream>>>(keys1, pos, L.m, n_nodes, L.cb, diag_val, nnz, col_idx,
-                                                                reinterpret_cast<float2*>(val));
-        MH_LAUNCH_CHECK("emit_diagonal");
-    }
+    Work W = cut(workspace, L, weighted);
+    int rc = fill_sorted(L, W, 0, n_nodes, q, max_eigen, nnz, W.dinv, col_idx, val, stream);
+    if (rc != MH_OK) return rc;
     if (dinv_out && n_nodes > 0)
-        MH_HIP(hipMemcpyAsync(dinv_out, dinv, size_t(n_nodes) * 4, hipMemcpyDeviceToDevice, stream));
+        MH_HIP(hipMemcpyAsync(dinv_out, W.dinv, size_t(n_nodes) * 4, hipMemcpyDeviceToDevice, stream));
     return MH_OK;
+}
+
+// ---- one rank's row block of the Laplacian ---------------------------------------------------------
+extern "C" size_t mh_lap_block_workspace_bytes(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int weighted) {
+    if (n_fwd < 0 || n_bwd < 0 || n_nodes < 0) return 0;
+    return make_layout(n_fwd + n_bwd, n_nodes, weighted != 0).total;
+}
+
+extern "C" int mh_lap_block_count(const void* fwd_row, const void* fwd_col, const float* fwd_w, int64_t n_fwd,
+                                  const void* bwd_row, const void* bwd_col, const float* bwd_w, int64_t n_bwd, int idx64,
+                                  int weighted_, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
+                                  void* workspace, size_t workspace_bytes, int32_t* row_ptr_block, float* dinv_block,
+                                  int64_t* nnz_host, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MH_REQUIRE(n_fwd >= 0 && n_bwd >= 0 && n_nodes >= 0, "negative size");
+    MH_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= n_nodes, "row block [%d, %d) outside [0, %d]", row_lo, row_hi, n_nodes);
+    MH_REQUIRE((n_fwd == 0 || (fwd_row && fwd_col)) && (n_bwd == 0 || (bwd_row && bwd_col)), "row/col is null");
+    MH_REQUIRE(workspace && row_ptr_block && nnz_host, "workspace/row_ptr_block/nnz_host is null");
+    MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
+    const bool weighted = weighted_ != 0;
+    MH_REQUIRE(weighted || (!fwd_w && !bwd_w), "weights passed to an unweighted build");
+    Layout L = make_layout(n_fwd + n_bwd, n_nodes, weighted);
+    Work W = cut(workspace, L, weighted);
+    int rc = prepare(L, workspace, workspace_bytes, W, row_hi - row_lo, stream);
+    if (rc != MH_OK) return rc;
+    const int diag = (float(2.0 / max_eigen) * 1.0f - 1.0f) != 0.0f;
+    EdgeList f{fwd_row, fwd_col, fwd_w, n_fwd, 0}, b{bwd_row, bwd_col, bwd_w, n_bwd, 0};
+    rc = records_and_sort(L, W, f, b, idx64, weighted, n_nodes, row_lo, row_hi, stream);
+    if (rc != MH_OK) return rc;
+    return count_sorted(L, W, weighted, n_nodes, row_lo, row_hi, diag, row_ptr_block, dinv_block, nnz_host, stream);
+}
+
+extern "C" int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double q,
+                                 double max_eigen, int weighted_, void* workspace, size_t workspace_bytes, int64_t nnz,
+                                 const float* dinv_full, int32_t* col_idx, float* val, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MH_REQUIRE(nnz >= 0 && n_fwd >= 0 && n_bwd >= 0 && n_nodes >= 0 && workspace, "bad size or null workspace");
+    MH_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= n_nodes, "row block [%d, %d) outside [0, %d]", row_lo, row_hi, n_nodes);
+    MH_REQUIRE(max_eigen > 0.0, "max_eigen must be positive");
+    MH_REQUIRE(dinv_full || n_nodes == 0, "dinv_full is null");
+    const bool weighted = weighted_ != 0;
+    Layout L = make_layout(n_fwd + n_bwd, n_nodes, weighted);
+    if (workspace_bytes < L.total)
+        return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
+    Work W = cut(workspace, L, weighted);
+    return fill_sorted(L, W, row_lo, row_hi, q, max_eigen, nnz, dinv_full, col_idx, val, stream);
 }

@@ -133,8 +133,13 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
             peers &= bit ? bal : ~bal;
         }
         const uint32_t r = __popcll(peers & lt);
+        // cnt[w][*] is private to this wavefront: every lane of a digit group reads the running count, then the
+        // group's lowest lane advances it for the next round.  The wave barriers keep the compiler from moving
+        // the LDS store across the other lanes' loads (the lanes of a wave execute in lockstep).
         const uint32_t base = cnt[w][d];
+        __builtin_amdgcn_wave_barrier();
         if (ok && r == 0) cnt[w][d] = base + uint32_t(__popcll(peers));   // lowest lane of the group
+        __builtin_amdgcn_wave_barrier();
         rank[i] = base + r;
     }
     __syncthreads();

@@ -251,6 +251,61 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> lap_build(const Tensor& row, const Te
     return std::make_tuple(row_ptr, col_idx, val, dinv);
 }
 
+// One rank's row block, phase 1: (workspace, row_ptr_block, dinv_block, nnz).  The workspace goes back into
+// lap_block_fill once the ranks have gathered each other's dinv_block.
+std::tuple<Tensor, Tensor, Tensor, int64_t> lap_block_count(const Tensor& fwd_row, const Tensor& fwd_col, const OptTensor& fwd_w,
+                                                            const Tensor& bwd_row, const Tensor& bwd_col, const OptTensor& bwd_w,
+                                                            int64_t n_nodes, int64_t row_lo, int64_t row_hi, double max_eigen) {
+    const c10::DeviceGuard guard(fwd_row.device());
+    const Tensor* idx[4] = {&fwd_row, &fwd_col, &bwd_row, &bwd_col};
+    for (const Tensor* t : idx) {
+        need_cuda(*t, "edge list");
+        TORCH_CHECK(t->scalar_type() == fwd_row.scalar_type() && t->is_contiguous() && t->dim() == 1,
+                    "edge lists must be contiguous vectors of one integer type");
+    }
+    TORCH_CHECK(fwd_row.scalar_type() == at::kInt || fwd_row.scalar_type() == at::kLong, "edge lists must be int32 or int64");
+    TORCH_CHECK(fwd_row.numel() == fwd_col.numel() && bwd_row.numel() == bwd_col.numel(), "row/col lengths differ");
+    TORCH_CHECK(n_nodes >= 0 && n_nodes <= INT32_MAX && 0 <= row_lo && row_lo <= row_hi && row_hi <= n_nodes, "bad row block");
+    const int64_t n_fwd = fwd_row.numel(), n_bwd = bwd_row.numel();
+    auto weights = [](const OptTensor& w, int64_t n) -> const float* {
+        if (!w.has_value() || !w->defined()) return nullptr;
+        need_cuda(*w, "edge_weight");
+        TORCH_CHECK(w->scalar_type() == at::kFloat && w->is_contiguous() && w->numel() == n,
+                    "edge_weight must be contiguous float32 of the list's length");
+        return n ? w->data_ptr<float>() : nullptr;
+    };
+    const float* fw = weights(fwd_w, n_fwd);
+    const float* bw = weights(bwd_w, n_bwd);
+    const int weighted = (fwd_w.has_value() && fwd_w->defined()) || (bwd_w.has_value() && bwd_w->defined());
+    const size_t ws_bytes = mh_lap_block_workspace_bytes(n_fwd, n_bwd, int32_t(n_nodes), weighted);
+    Tensor ws = at::empty({int64_t(ws_bytes)}, fwd_row.options().dtype(at::kByte));
+    Tensor row_ptr = at::empty({row_hi - row_lo + 1}, fwd_row.options().dtype(at::kInt));
+    Tensor dinv = at::empty({row_hi - row_lo}, fwd_row.options().dtype(at::kFloat));
+    int64_t nnz = 0;
+    check_rc(mh_lap_block_count(fwd_row.data_ptr(), fwd_col.data_ptr(), fw, n_fwd, bwd_row.data_ptr(), bwd_col.data_ptr(), bw, n_bwd,
+                                fwd_row.scalar_type() == at::kLong, weighted, int32_t(n_nodes), int32_t(row_lo), int32_t(row_hi),
+                                max_eigen, ws.data_ptr(), ws_bytes, row_ptr.data_ptr<int32_t>(), dinv.data_ptr<float>(), &nnz,
+                                stream_of(fwd_row)), "lap_block_count");
+    return std::make_tuple(ws, row_ptr, dinv, nnz);
+}
+
+// phase 2: (col_idx with global column ids, val [nnz, 2]) of the block
+std::tuple<Tensor, Tensor> lap_block_fill(const Tensor& ws, int64_t n_fwd, int64_t n_bwd, int64_t n_nodes, int64_t row_lo,
+                                          int64_t row_hi, double q, double max_eigen, bool weighted, int64_t nnz,
+                                          const Tensor& dinv_full) {
+    const c10::DeviceGuard guard(ws.device());
+    need_cuda(ws, "workspace"); need_cuda(dinv_full, "dinv_full");
+    TORCH_CHECK(ws.scalar_type() == at::kByte && ws.is_contiguous(), "workspace must be the tensor lap_block_count returned");
+    TORCH_CHECK(dinv_full.scalar_type() == at::kFloat && dinv_full.is_contiguous() && dinv_full.numel() == n_nodes,
+                "dinv_full must be contiguous float32 [n_nodes]");
+    Tensor col_idx = at::empty({nnz}, ws.options().dtype(at::kInt));
+    Tensor val = at::empty({nnz, 2}, ws.options().dtype(at::kFloat));
+    check_rc(mh_lap_block_fill(n_fwd, n_bwd, int32_t(n_nodes), int32_t(row_lo), int32_t(row_hi), q, max_eigen, weighted ? 1 : 0,
+                               ws.data_ptr(), size_t(ws.numel()), nnz, dinv_full.data_ptr<float>(), col_idx.data_ptr<int32_t>(),
+                               val.data_ptr<float>(), stream_of(ws)), "lap_block_fill");
+    return std::make_tuple(col_idx, val);
+}
+
 // ---- layout / activation -----------------------------------------------------------------------
 void pack(const Tensor& real, const Tensor& imag, Tensor& out) {
     const c10::DeviceGuard guard(out.device());
@@ -370,6 +425,10 @@ TORCH_LIBRARY(magnet, m) {
           "bool relu, Tensor(c!)? mask, Tensor? plan, int n_long, int n_chunks, int chunk, Tensor(d!)? scratch) -> ()");
     m.def("lap_build(Tensor row, Tensor col, Tensor? weight, int n_nodes, float q, float max_eigen, bool gcn_appr) -> "
           "(Tensor, Tensor, Tensor, Tensor)");
+    m.def("lap_block_count(Tensor fwd_row, Tensor fwd_col, Tensor? fwd_w, Tensor bwd_row, Tensor bwd_col, Tensor? bwd_w, "
+          "int n_nodes, int row_lo, int row_hi, float max_eigen) -> (Tensor, Tensor, Tensor, int)");
+    m.def("lap_block_fill(Tensor ws, int n_fwd, int n_bwd, int n_nodes, int row_lo, int row_hi, float q, float max_eigen, "
+          "bool weighted, int nnz, Tensor dinv_full) -> (Tensor, Tensor)");
     m.def("pack(Tensor real, Tensor imag, Tensor(a!) out) -> ()");
     m.def("unpack(Tensor p, Tensor(a!) re, Tensor(b!) im) -> ()");
     m.def("gather_rows(Tensor x, Tensor idx, Tensor(a!) buf) -> ()");
@@ -389,6 +448,8 @@ TORCH_LIBRARY_IMPL(magnet, CUDA, m) {
     m.impl("cheb_terms_", &cheb_terms_);
     m.impl("clenshaw", &clenshaw);
     m.impl("lap_build", &lap_build);
+    m.impl("lap_block_count", &lap_block_count);
+    m.impl("lap_block_fill", &lap_block_fill);
     m.impl("pack", &pack);
     m.impl("unpack", &unpack);
     m.impl("gather_rows", &gather_rows);

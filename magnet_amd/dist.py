@@ -5,9 +5,8 @@ The reference is single-device (src/sparse_Magnet.py:23-24); this module is the 
 extension of its propagation (src/layer/sparse_magnet.py:50-72).  Two decompositions:
 
 * RowPartition  — rows of the Laplacian and of the features are cut into blocks; every order
-  exchanges the freshly computed blocks (the halo of a graph without locality is every row).
-  No communication at all for K = 1, and the natural choice when a partition keeps most
-  neighbours local.
+  exchanges the halo rows (on a graph without locality that is nearly every row).  Memory and
+  set-up scale with 1/world; the natural choice when a partition keeps most neighbours local.
 * ColumnSharded — every rank holds the whole Laplacian and a slice of the feature columns; the
   recursion needs no communication and one all-to-all per layer turns column slices into row
   blocks for the weight GEMM.  (K-1)*world/(K+1) times fewer bytes on a graph without locality.
@@ -15,24 +14,25 @@ extension of its propagation (src/layer/sparse_magnet.py:50-72).  Two decomposit
 Row partition
 -------------
 * Rows of the Laplacian (and of every feature matrix) are cut into `world` contiguous blocks
-  balanced by work (nonzeros + rows).  Rank p computes rows [b_p, b_{p+1}) of each order.
-* Every rank keeps FULL-height feature buffers [N, 2, F] indexed by global node id (288 GB of
-  HBM make that affordable: 20 GB per order at N = 10M, F = 256), so the CSR keeps its global
-  column ids.  After computing its block of Z_k a rank sends every peer the rows that peer's block
-  references (its boundary rows for that peer) and receives the rows it references itself.  On a
-  graph without locality that is the whole block, which then travels in place with no packing; on
-  a graph with locality only the boundary rows travel, packed by a row-gather kernel and scattered
-  into place on arrival.  The transfers are point-to-point sends/receives issued as one batch: on
-  the fully connected xGMI mesh every pair of GPUs has its own link, so all 7 peers are served
-  concurrently (a ring would push 7x the bytes through one link).
-* To overlap the exchange with compute the local block of the Laplacian is split by COLUMN into
-  L_int (columns inside the rank's own row block: operands already local) and L_ext (all other
-  columns).  Order k runs  Z_k[blk] = a L_int Z_{k-1} + b Z_{k-2}[blk]  while the exchange of
-  Z_{k-1} is still in flight, waits for it, then adds  a L_ext Z_{k-1}.  That covers more than
-  the interior-row split (rows without any remote column): every nonzero with a local column
+  balanced by work (nonzeros + rows).  Rank p computes rows [b_p, b_{p+1}) of each order and holds
+  nothing else of the graph: it BUILDS only its own row block, from the edges incident to its rows
+  (build_row_block -> mh_lap_block_*; the ranks exchange one vector of d^-1/2).
+* Feature buffers are COMPACT, [n_local + n_halo, 2, F]: the rank's rows, then its halo (the remote rows
+  its block references, ascending by global id and therefore grouped by owner).  The block's columns are
+  renumbered to that buffer by the halo plan (mh_halo_plan_*).  After computing its rows of Z_k a rank
+  sends every peer the rows that peer references (packed by a row-gather kernel; in place when the peer
+  references the whole block) and receives its own halo rows straight into their slice of the buffer.
+  The transfers are point-to-point sends/receives issued as one batch: on the fully connected xGMI mesh
+  every pair of GPUs has its own link, so all 7 peers are served concurrently (a ring would push 7x the
+  bytes through one link).
+* To overlap the exchange with compute the block is split by COLUMN into L_int (own columns: operands
+  already local) and L_ext (halo columns).  Order k runs  Z_k[own] = a L_int Z_{k-1} + b Z_{k-2}[own]
+  while the exchange of Z_{k-1} is still in flight, waits for it, then adds  a L_ext Z_{k-1}.  That covers
+  more than the interior-row split (rows without any remote column): every nonzero with a local column
   overlaps, whatever row it sits in.
 * The weight GEMM and the bias act on rows independently, so the output block needs no exchange;
-  a conv of K orders performs K-1 exchanges.  Weight gradients are all-reduced (tiny).
+  a conv of K orders performs K exchanges (its input's halo and K-1 intermediate orders).  Weight
+  gradients are all-reduced (tiny).
 """
 import torch
 import torch.distributed as dist
@@ -77,23 +77,6 @@ def split_columns(row_ptr, col_idx, val, c0, c1):
     return out[0], out[1]
 
 
-def exchange_blocks(full, bounds, rank, world, group=None):
-    """Send rows [bounds[rank], bounds[rank+1]) of `full` to every peer and receive every peer's
-    block into its place.  Returns the list of work handles (wait on all before reading remote rows)."""
-    if world == 1:
-        return []
-    mine = full[bounds[rank]:bounds[rank + 1]]
-    ops = []
-    for step in range(1, world):                         # staggered peers: rank r talks to r+step / r-step
-        to, frm = (rank + step) % world, (rank - step) % world
-        if mine.numel():
-            ops.append(dist.P2POp(dist.isend, mine, to, group))
-        blk = full[bounds[frm]:bounds[frm + 1]]
-        if blk.numel():
-            ops.append(dist.P2POp(dist.irecv, blk, frm, group))
-    return dist.batch_isend_irecv(ops) if ops else []
-
-
 def wait_all(works):
     for w in works:
         w.wait()
@@ -125,10 +108,52 @@ class HipRowMover:
         scatter_rows(buf, idx, x)
 
 
+def halo_plan_torch(col_idx, n_cols, c0, c1, bounds):
+    """Plain tensor restatement of mh_halo_plan_* (what the gloo rehearsal on CPU tensors uses, and what the
+    GPU tests compare the kernels with): ascending remote column ids, their grouping by owning rank, and the
+    columns renumbered to [own rows | halo rows]."""
+    remote = (col_idx < c0) | (col_idx >= c1)
+    halo_ids = torch.unique(col_idx[remote].long())
+    peer_ptr = torch.searchsorted(halo_ids, bounds.long())
+    slot = torch.searchsorted(halo_ids, col_idx.long())
+    col_local = torch.where(remote, (c1 - c0) + slot, col_idx.long() - c0)
+    return halo_ids.to(torch.int32), peer_ptr.to(torch.int32), col_local.to(torch.int32)
+
+
+def _halo_plan(col_idx, n_cols, c0, c1, bounds):
+    if col_idx.is_cuda:
+        from .laplacian import halo_plan
+        return halo_plan(col_idx, n_cols, c0, c1, bounds)
+    return halo_plan_torch(col_idx, n_cols, c0, c1, bounds)
+
+
+def exchange_index_lists(send, rank, world, group=None):
+    """send[p]: int32 tensor for rank p (entry `rank` ignored) -> list of what every rank sent to this one.
+    Lengths travel first (one all_gather), then the lists as batched point-to-point transfers."""
+    dev = send[(rank + 1) % world].device if world > 1 else None
+    recv = [None] * world
+    if world == 1:
+        return recv
+    counts = torch.tensor([0 if p == rank else int(send[p].numel()) for p in range(world)], dtype=torch.int64, device=dev)
+    table = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(table, counts, group=group)
+    ops = []
+    for step in range(1, world):
+        to, frm = (rank + step) % world, (rank - step) % world
+        recv[frm] = torch.empty(int(table[frm][rank]), dtype=torch.int32, device=dev)
+        if send[to].numel():
+            ops.append(dist.P2POp(dist.isend, send[to].contiguous(), to, group))
+        if recv[frm].numel():
+            ops.append(dist.P2POp(dist.irecv, recv[frm], frm, group))
+    if ops:
+        wait_all(dist.batch_isend_irecv(ops))
+    return recv
+
+
 def exchange_volumes(row_ptr, col_idx, n, n_features, K, world):
-    """Feature floats one rank sends per conv under the two decompositions, largest rank:
-    (row partition: K-1 exchanges of the rows its peers reference; column sharding: one all-to-all of the
-    K+1 orders).  Plain tensor code, every rank computes the same numbers from the replicated CSR."""
+    """Feature floats one rank receives per conv under the two decompositions, largest rank:
+    (row partition: K exchanges of the remote rows its block references — the input's halo and K-1 intermediate
+    orders; column sharding: one all-to-all of the K+1 orders).  Plain tensor code on a replicated CSR."""
     bounds = partition_bounds(row_ptr, world)
     rows_worst = 0
     for p in range(world):
@@ -136,121 +161,129 @@ def exchange_volumes(row_ptr, col_idx, n, n_features, K, world):
         cols = col_idx[a:b]
         remote = torch.unique(cols[(cols < bounds[p]) | (cols >= bounds[p + 1])])   # rows of other ranks that rank p gathers
         rows_worst = max(rows_worst, int(remote.numel()))
-    rows_floats = max(K - 1, 0) * rows_worst * 2 * n_features       # received (= sent by symmetry of the pattern, at worst)
-    cols_floats = (K + 1) * n * 2 * n_features * (world - 1) // (world * world)
-    return rows_floats, cols_floats
+    return row_partition_floats(rows_worst, n_features, K), column_sharding_floats(n, n_features, K, world)
+
+
+def row_partition_floats(n_halo, n_features, K):
+    """Floats a rank receives per conv in the row partition: its halo rows, once per propagated order."""
+    return max(K, 0) * n_halo * 2 * n_features
+
+
+def column_sharding_floats(n, n_features, K, world):
+    return (K + 1) * n * 2 * n_features * (world - 1) // (world * world)
 
 
 def choose_strategy(row_ptr, col_idx, n, n_features, K, world):
-    """'rows' or 'cols' for a conv on `world` GPUs: the row partition needs no exchange at all for K <= 1
-    and little on graphs whose neighbours have nearby ids (only boundary rows travel); on a graph without
-    locality every row is a boundary row and column sharding moves (K-1) world / (K+1) times less."""
-    if world == 1 or K <= 1 or n_features % (4 * world) != 0:
+    """'rows' or 'cols' for a conv on `world` GPUs: the row partition moves little on graphs whose neighbours
+    have nearby ids (only boundary rows travel); on a graph without locality every row is a boundary row and
+    column sharding moves about K world / (K+1) times less."""
+    if world == 1 or K < 1 or n_features % (4 * world) != 0:
         return 'rows'
     rows_floats, cols_floats = exchange_volumes(row_ptr, col_idx, n, n_features, K, world)
     return 'rows' if rows_floats <= cols_floats else 'cols'
 
 
 class RowPartition:
-    """The rank's share of a Laplacian: its row block split into local-column and remote-column
-    parts, and the exchange of freshly computed rows.  `make_operator(rp, ci, val, n_cols)` turns CSR
-    tensors into an object with .spmm(X, out=, alpha=, z1=, beta1=) — the HIP MagneticLaplacian in
-    production.
+    """One rank's share of a row-partitioned Laplacian, in COMPACT form: memory and set-up scale with 1/world.
 
-    Exchange: for every peer p the rank knows `give[p]` (its rows that some row of p's block
-    references: the boundary rows p needs) and `need[p]` (the rows of p's block its own L_ext
-    references).  When a peer needs most of the block (>= dense_fraction of its rows — always the case
-    on a graph without locality) the whole block is sent in place; otherwise only the boundary rows
-    travel: packed with the row-gather kernel, received into a staging buffer and scattered into
-    the full-height buffer before the remote-column SpMM runs."""
+    The rank holds the CSR of its row block [r0, r1) only.  Feature matrices are [n_local + n_halo, 2, F]:
+    first the rank's own rows, then its halo — the remote rows its block references, ascending by global id
+    and therefore grouped by owning rank.  The block's columns are renumbered to that buffer (mh_halo_plan_*:
+    own column c -> c - r0, remote c -> n_local + slot), and split into L_int (own columns: operands local)
+    and L_ext (halo columns).  `make_operator(rp, ci, val, n_cols)` turns CSR tensors into an object with
+    .spmm(X, out=, alpha=, z1=, beta1=) — the HIP MagneticLaplacian in production.
 
-    def __init__(self, row_ptr, col_idx, val, n, rank, world, make_operator, group=None, row_mover=None,
-                 dense_fraction=0.75):
+    Exchange of an order: every peer p gets the rows of this rank it references (`give[p]`, learned from p's
+    halo plan at set-up; packed by the row-gather kernel, or sent in place when p references the whole
+    block) and this rank receives, from every peer, its halo rows of that peer straight into their slice of
+    the buffer — contiguous, no unpacking.  Point-to-point transfers issued as one batch: on the fully
+    connected xGMI mesh every pair of GPUs has its own link.  Order k runs
+    Z_k[own] = a L_int Z_{k-1} + b Z_{k-2}[own] while the halo of Z_{k-1} is in flight, waits, then adds
+    a L_ext Z_{k-1}."""
+
+    def __init__(self, rp_blk, ci_blk, val_blk, n, bounds, rank, world, make_operator, group=None, row_mover=None,
+                 exchange_lists=exchange_index_lists):
         self.n, self.rank, self.world, self.group = n, rank, world, group
-        self.mover = row_mover or (HipRowMover if row_ptr.is_cuda else TorchRowMover)
-        self.bounds = b = partition_bounds(row_ptr, world)
+        self.mover = row_mover or (HipRowMover if rp_blk.is_cuda else TorchRowMover)
+        self.bounds = b = [int(x) for x in bounds]
         self.r0, self.r1 = b[rank], b[rank + 1]
-        rp, ci, v = slice_rows(row_ptr, col_idx, val, self.r0, self.r1)
-        self.local_nnz = int(ci.numel())
-        (rpi, cii, vi), (rpe, cie, ve) = split_columns(rp, ci, v, self.r0, self.r1)
-        self.L_int = make_operator(rpi, cii, vi, n)
-        self.L_ext = make_operator(rpe, cie, ve, n)
-        # boundary sets; every rank derives them from the same CSR, so sender and receiver agree
-        dev = row_ptr.device
-        self.give, self.need = [None] * world, [None] * world
-        cols_ext = cie.long()
-        for p in range(world):
-            if p == rank:
-                continue
-            m = torch.zeros(b[p + 1] - b[p], dtype=torch.bool, device=dev)          # rows of p that I reference
-            sel = cols_ext[(cols_ext >= b[p]) & (cols_ext < b[p + 1])]
-            m[sel - b[p]] = True
-            need = m.nonzero().squeeze(1) + b[p]
-            self.need[p] = None if need.numel() >= dense_fraction * max(b[p + 1] - b[p], 1) else need.to(torch.int32)
-            a, z = int(row_ptr[b[p]]), int(row_ptr[b[p + 1]])                      # my rows that p references
-            cp = col_idx[a:z].long()
-            m = torch.zeros(self.r1 - self.r0, dtype=torch.bool, device=dev)
-            m[cp[(cp >= self.r0) & (cp < self.r1)] - self.r0] = True
-            give = m.nonzero().squeeze(1) + self.r0
-            self.give[p] = None if give.numel() >= dense_fraction * max(self.r1 - self.r0, 1) else give.to(torch.int32)
+        self.n_local = self.r1 - self.r0
+        if rp_blk.numel() != self.n_local + 1:
+            raise ValueError('the CSR block has %d rows, the bounds give this rank %d' % (rp_blk.numel() - 1, self.n_local))
+        dev = rp_blk.device
+        self.local_nnz = int(ci_blk.numel())
+        halo_ids, peer_ptr, col_local = _halo_plan(ci_blk, n, self.r0, self.r1, torch.tensor(b, dtype=torch.int32, device=dev))
+        self.halo_ids, self.peer_ptr = halo_ids, [int(x) for x in peer_ptr.tolist()]
+        self.n_halo = int(halo_ids.numel())
+        self.n_buf = self.n_local + self.n_halo
+        (rpi, cii, vi), (rpe, cie, ve) = split_columns(rp_blk, col_local, val_blk, 0, self.n_local)
+        self.L_int = make_operator(rpi, cii, vi, self.n_buf)
+        self.L_ext = make_operator(rpe, cie, ve, self.n_buf)
+        # tell every peer which of its rows this rank gathers (as row numbers inside the peer's block)
+        self.need = [None if p == rank else (halo_ids[self.peer_ptr[p]:self.peer_ptr[p + 1]] - b[p]).to(torch.int32)
+                     for p in range(world)]
+        # give[p]: the rows of this rank's block that peer p gathers = need[rank] of peer p
+        self.give = exchange_lists(self.need, rank, world, group)
+        self.comm_enabled = True          # False: skip the transfers (timing the compute alone)
 
-    def block(self, full):
-        return full[self.r0:self.r1]
+    @classmethod
+    def from_global(cls, row_ptr, col_idx, val, n, rank, world, make_operator, group=None, row_mover=None, bounds=None):
+        """The rank's partition cut out of a CSR that the rank holds whole."""
+        bounds = bounds or partition_bounds(row_ptr, world)
+        rp, ci, v = slice_rows(row_ptr, col_idx, val, bounds[rank], bounds[rank + 1])
+        return cls(rp, ci, v, n, bounds, rank, world, make_operator, group, row_mover)
 
-    def exchange(self, full):
-        """Start sending my freshly computed rows and receiving the peers'.  Returns a handle for
-        finish_exchange()."""
-        if self.world == 1:
+    def new_buffer(self, f, device, dtype=torch.float32):
+        return torch.empty((self.n_buf, 2, f), dtype=dtype, device=device)
+
+    def block(self, buf):
+        """The rank's own rows of a feature buffer."""
+        return buf[:self.n_local]
+
+    def sent_rows(self):
+        """Rows this rank sends per exchange (over all peers)."""
+        return sum(int(g.numel()) for p, g in enumerate(self.give) if p != self.rank and g is not None)
+
+    def exchange(self, buf):
+        """Start sending the peers their halo rows of buf's own block and receiving this rank's halo.
+        Returns a handle for finish_exchange()."""
+        if self.world == 1 or not self.comm_enabled:
             return None
-        b, ops, staged = self.bounds, [], []
-        f = full.size(2)
+        ops, staged = [], []
+        nl, pp = self.n_local, self.peer_ptr
         for step in range(1, self.world):
             to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
-            if self.give[to] is None:
-                mine = full[self.r0:self.r1]
-            else:
-                mine = self.mover.gather(full, self.give[to])
-            if mine.numel():
+            g = self.give[to]
+            if g.numel():
+                mine = buf[:nl] if g.numel() == nl else self.mover.gather(buf, g)   # ascending + complete = the block itself
                 ops.append(dist.P2POp(dist.isend, mine, to, self.group))
                 staged.append(mine)                                  # keep the send buffer alive
-            if self.need[frm] is None:
-                blk = full[b[frm]:b[frm + 1]]
-                if blk.numel():
-                    ops.append(dist.P2POp(dist.irecv, blk, frm, self.group))
-            elif self.need[frm].numel():
-                buf = torch.empty((self.need[frm].numel(), 2, f), dtype=full.dtype, device=full.device)
-                ops.append(dist.P2POp(dist.irecv, buf, frm, self.group))
-                staged.append((buf, self.need[frm]))
+            if pp[frm + 1] > pp[frm]:
+                ops.append(dist.P2POp(dist.irecv, buf[nl + pp[frm]:nl + pp[frm + 1]], frm, self.group))
         works = dist.batch_isend_irecv(ops) if ops else []
-        return (works, staged, full)
+        return (works, staged)
 
     def finish_exchange(self, handle):
-        """Wait for an exchange and move staged boundary rows into place."""
-        if not handle:
-            return
-        works, staged, full = handle
-        wait_all(works)
-        for item in staged:
-            if isinstance(item, tuple):
-                self.mover.scatter(item[0], item[1], full)
+        if handle:
+            wait_all(handle[0])
 
     def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=None):
-        """z_out[blk] = alpha * (L z_prev)[blk] + beta * z_prev2[blk].  `pending` is the handle of the
-        exchange that completes z_prev; only the remote-column part waits for it."""
+        """z_out[own] = alpha * (L z_prev)[own] + beta * z_prev2[own].  `pending` is the handle of the
+        exchange that completes z_prev's halo; only the halo-column part waits for it."""
         blk = self.block(z_out)
         self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta)
         self.finish_exchange(pending)
-        self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
+        if self.n_halo:
+            self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
         return blk
 
-    def cheb_terms(self, x_full, n_terms, buffers=None):
-        """[T_0 x, ..., T_{n-1} x] as full-height buffers of which this rank's row block (and, for
-        all but the last order, every row this rank references) is valid; x_full must hold every row
-        this rank references."""
-        zs = [x_full]
-        pending = None
+    def cheb_terms(self, x_buf, n_terms, buffers=None, halo_valid=False):
+        """[T_0 x, ..., T_{n-1} x] as compact buffers whose own rows are valid (and, for all but the last
+        order, the halo).  x_buf holds the rank's rows of x; its halo is fetched first unless `halo_valid`."""
+        zs = [x_buf]
+        pending = None if (halo_valid or n_terms < 2) else self.exchange(x_buf)
         for k in range(1, n_terms):
-            z = buffers[k - 1] if buffers is not None else torch.empty_like(x_full)
+            z = buffers[k - 1] if buffers is not None else torch.empty_like(x_buf)
             if k == 1:
                 self.propagate(zs[0], z, 1.0, pending=pending)
             else:
@@ -260,33 +293,97 @@ class RowPartition:
         return zs
 
 
-class RowPartitionedConv:
-    """One MagNetConv forward on a row-partitioned graph (what bench.py times with --gpus N > 1):
-    K propagation orders with K-1 block exchanges, then the row-local weight GEMMs and bias."""
+# ---------------------------------------------------------------------------------------------
+# distributed set-up: every rank builds its own row block
+# ---------------------------------------------------------------------------------------------
+def bounds_from_degrees(deg, world, row_cost=2):
+    """Row boundaries balanced by (records per row + row_cost): `deg[i]` = out-degree + in-degree of node i,
+    an upper bound of the row's nonzeros that is known before the Laplacian exists."""
+    n = deg.numel()
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=deg.device)
+    rp[1:] = torch.cumsum(deg.to(torch.int64), 0)
+    return partition_bounds(rp, world, row_cost)
 
-    def __init__(self, lap, in_c, out_c, K, rank, world, device, seed=1):
+
+def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None, max_eigen=2.0):
+    """This rank's row block of the magnetic Laplacian, built from the edges incident to its rows
+    (mh_lap_block_*), plus the bounds of all ranks.  `edge_chunks()` returns an iterator over
+    (row, col[, weight]) device tensors that together list every edge, in the same order on every rank
+    (a replicated list or a seeded generator); it is called once for the degrees when `bounds` is not given and
+    once for the records.  Ranks exchange only d^-1/2 (an all-reduce of n floats in which every node is
+    non-zero on exactly one rank, so the sum is exact).  Returns (MagneticLaplacian block with global
+    column ids, bounds)."""
+    from .laplacian import LaplacianBlockBuild
+    dev = None
+    if bounds is None:
+        deg = None
+        for chunk in edge_chunks():
+            row, col = chunk[0], chunk[1]
+            dev = row.device
+            d = torch.bincount(row.long(), minlength=n) + torch.bincount(col.long(), minlength=n)
+            deg = d if deg is None else deg + d
+        if deg is None:
+            raise ValueError('edge_chunks() yielded nothing')
+        bounds = bounds_from_degrees(deg, world)
+        del deg
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    parts = [[], [], [], [], [], []]                 # fwd row, col, w ; bwd row, col, w
+    weighted = False
+    for chunk in edge_chunks():
+        row, col = chunk[0], chunk[1]
+        w = chunk[2] if len(chunk) > 2 else None
+        weighted = weighted or w is not None
+        dev = row.device
+        f = (row >= r0) & (row < r1)
+        b = (col >= r0) & (col < r1)
+        parts[0].append(row[f]); parts[1].append(col[f])
+        parts[3].append(row[b]); parts[4].append(col[b])
+        if w is not None:
+            parts[2].append(w[f]); parts[5].append(w[b])
+    cat = lambda xs: torch.cat(xs) if len(xs) > 1 else xs[0]
+    fwd = (cat(parts[0]), cat(parts[1])) + ((cat(parts[2]),) if weighted else ())
+    bwd = (cat(parts[3]), cat(parts[4])) + ((cat(parts[5]),) if weighted else ())
+    del parts
+    build = LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=max_eigen)
+    del fwd, bwd
+    dinv = torch.zeros(n, dtype=torch.float32, device=dev)
+    dinv[r0:r1] = build.dinv_block
+    if world > 1:
+        dist.all_reduce(dinv, group=group)
+    return build.finish(dinv, q), bounds
+
+
+class RowPartitionedConv:
+    """One MagNetConv forward on a row-partitioned graph (what bench.py times with --gpus N > 1 in the row
+    layout): the input's halo exchange, K propagation orders with K-1 more exchanges, then the row-local weight
+    GEMM over the orders side by side and the bias.  `lap_block` is the rank's row block (global column ids),
+    e.g. from build_row_block."""
+
+    def __init__(self, lap_block, bounds, in_c, out_c, K, rank, world, device, seed=1, group=None):
         from .laplacian import MagneticLaplacian
 
         def make(rp, ci, v, n_cols):
             return MagneticLaplacian(rp, ci, v, n_cols)
 
-        self.part = RowPartition(lap.row_ptr, lap.col_idx, lap.val, lap.n_rows, rank, world, make)
+        self.part = RowPartition(lap_block.row_ptr, lap_block.col_idx, lap_block.val, lap_block.n_cols, bounds, rank, world,
+                                 make, group)
         self.K = K
         g = torch.Generator(device='cpu').manual_seed(seed)
         stdv = 1.0 / out_c ** 0.5
         self.weight = ((torch.rand(K + 1, in_c, out_c, generator=g) * 2 - 1) * stdv).to(device)
         self.bias = torch.zeros(1, out_c, device=device)
-        n = lap.n_rows
-        # every rank draws the same features, so the input is complete everywhere (replicated input)
-        gen = torch.Generator(device=device).manual_seed(seed)
-        self.x = torch.randn(n, 2, in_c, device=device, generator=gen)
-        self.buffers = [torch.empty_like(self.x) for _ in range(K)]
+        part = self.part
+        gen = torch.Generator(device=device).manual_seed(seed + 1000 * rank)
+        self.x = part.new_buffer(in_c, device)
+        part.block(self.x).copy_(torch.randn(part.n_local, 2, in_c, device=device, generator=gen))
+        self.x[part.n_local:].zero_()
+        self.buffers = [part.new_buffer(in_c, device) for _ in range(K)]
         self.launches = []
 
     def step(self):
         part = self.part
         zs = part.cheb_terms(self.x, self.K + 1, self.buffers)
-        rows = part.r1 - part.r0
+        rows = part.n_local
         blk = lambda z: part.block(z).reshape(rows * 2, z.size(2))
         out = torch.addmm(self.bias, blk(zs[0]), self.weight[0])
         for k in range(1, self.K + 1):
@@ -308,10 +405,12 @@ def column_bounds(n_features, world, quantum=4):
     return b
 
 
-def all_to_all_blocks(send, recv, rank, world, group=None):
+def all_to_all_blocks(send, recv, rank, world, group=None, enabled=True):
     """send[p] goes to rank p, recv[p] is filled by rank p (lists of contiguous tensors; entry `rank`
     is ignored).  Batched point-to-point: one direct transfer per GPU pair on the xGMI mesh."""
     ops = []
+    if not enabled:
+        return ops
     for step in range(1, world):
         to, frm = (rank + step) % world, (rank - step) % world
         if send[to].numel():
@@ -337,6 +436,7 @@ class ColumnSharded:
         self.c0, self.c1 = self.cb[rank], self.cb[rank + 1]
         self.rb = [n * p // world for p in range(world)] + [n]         # output row blocks
         self.r0, self.r1 = self.rb[rank], self.rb[rank + 1]
+        self.comm_enabled = True          # False: skip the transfers (timing the compute alone)
 
     def cheb_terms(self, x_slice, n_terms, after_each=None):
         """Column slices of [T_0 x, ..., T_{n-1} x]; `after_each(k, z)` is called as soon as order k
@@ -363,7 +463,7 @@ class ColumnSharded:
         recv = [send[p] if p == self.rank else
                 torch.empty((rows_me, 2, self.cb[p + 1] - self.cb[p]), dtype=z.dtype, device=z.device)
                 for p in range(self.world)]
-        return all_to_all_blocks(send, recv, self.rank, self.world, self.group), recv, z
+        return all_to_all_blocks(send, recv, self.rank, self.world, self.group, self.comm_enabled), recv, z
 
     def finish_regroup(self, handle):
         """-> [rows_me, 2, F] (my rows, all columns) of that order."""
@@ -413,7 +513,7 @@ class ColumnSharded:
                 ops.append(dist.P2POp(dist.isend, part, to, self.group))
             if recv[frm].numel():
                 ops.append(dist.P2POp(dist.irecv, recv[frm], frm, self.group))
-            if ops:
+            if ops and self.comm_enabled:
                 works += dist.batch_isend_irecv(ops)
         recv[self.rank] = block(self.rank)
         return works, recv, z

@@ -286,6 +286,55 @@ def build_magnetic_laplacian(row, col, size, q=0.25, max_eigen=2.0, gcn_appr=Fal
     return MagneticLaplacian(row_ptr, col_idx, val, int(size), q=q, dinv=dinv)
 
 
+class LaplacianBlockBuild:
+    """Two-phase build of ONE rank's row block [r0, r1) of the magnetic Laplacian (mh_lap_block_*):
+
+        b = LaplacianBlockBuild(fwd, bwd, n, r0, r1)      # fwd / bwd: (row, col[, weight]) of the edges whose
+                                                          # source / target lies in the block, in input order
+        b.dinv_block                                      # d^-1/2 of the block's rows -> gather over the ranks
+        lap = b.finish(dinv_full, q)                      # CSR of the block, GLOBAL column ids
+
+    The blocks of a partition, stacked, are bit for bit the CSR build_magnetic_laplacian returns."""
+
+    def __init__(self, fwd, bwd, size, r0, r1, max_eigen=2.0):
+        def norm(lst):
+            row, col = lst[0], lst[1]
+            w = lst[2] if len(lst) > 2 else None
+            require_cuda(row, col, w)
+            row, col = row.reshape(-1).contiguous(), col.reshape(-1).contiguous()
+            if w is not None:
+                w = w.reshape(-1).to(torch.float32).contiguous()
+            return row, col, w
+        fr, fc, fw = norm(fwd)
+        br, bc, bw = norm(bwd)
+        dt = torch.int64 if torch.int64 in (fr.dtype, fc.dtype, br.dtype, bc.dtype) else torch.int32
+        fr, fc, br, bc = (t.to(dt) for t in (fr, fc, br, bc))
+        if (fw is None) != (bw is None):          # one list weighted, the other not: unit weights for the other
+            fw = torch.ones(fr.numel(), device=fr.device) if fw is None else fw
+            bw = torch.ones(br.numel(), device=br.device) if bw is None else bw
+        self.n, self.r0, self.r1, self.max_eigen = int(size), int(r0), int(r1), float(max_eigen)
+        self.n_fwd, self.n_bwd, self.weighted = fr.numel(), br.numel(), fw is not None
+        with torch.cuda.device(fr.device):
+            self._ws, self.row_ptr, self.dinv_block, self.nnz = ops.lap_block_count(
+                fr, fc, fw, br, bc, bw, self.n, self.r0, self.r1, self.max_eigen)
+
+    def finish(self, dinv_full, q=0.25):
+        with torch.cuda.device(dinv_full.device):
+            col_idx, val = ops.lap_block_fill(self._ws, self.n_fwd, self.n_bwd, self.n, self.r0, self.r1, float(q),
+                                              self.max_eigen, self.weighted, self.nnz, dinv_full.contiguous())
+        self._ws = None
+        return MagneticLaplacian(self.row_ptr, col_idx, val, self.n, q=q, dinv=dinv_full)
+
+
+def halo_plan(col_idx, n_cols, c0, c1, bounds):
+    """(halo_ids, peer_ptr, col_local) of a row block whose CSR holds global column ids (mh_halo_plan_*):
+    the remote feature rows it gathers, grouped by owning rank, and its columns renumbered to a compact
+    [own rows | halo rows] buffer.  `bounds`: int32 device tensor [world + 1] of the ranks' row boundaries."""
+    require_cuda(col_idx, bounds)
+    with torch.cuda.device(col_idx.device):
+        return ops.halo_plan(col_idx.contiguous(), int(n_cols), int(c0), int(c1), bounds.to(torch.int32).contiguous())
+
+
 def powerlaw_edges(n_nodes, n_edges, seed, first_edge=0, device='cuda'):
     """Synthetic power-law digraph on the device (mh_powerlaw_edges): int32 src, dst."""
     src = torch.empty(n_edges, dtype=torch.int32, device=device)

@@ -77,14 +77,14 @@ def _worker(rank, world, port, n_terms, out_dir, banded=False):
     try:
         L, rp, ci, val = _banded_graph() if banded else _graph()
         n = L.shape[0]
-        part = D.RowPartition(rp, ci, val, n, rank, world, ScipyOperator)
+        part = D.RowPartition.from_global(rp, ci, val, n, rank, world, ScipyOperator)
         x = torch.randn(n, 2, 5, generator=torch.Generator().manual_seed(0))
-        zs = part.cheb_terms(x, n_terms)
-        blocks = [part.block(z).clone() for z in zs]
-        # after an order's exchange every row this rank references is valid (all rows when blocks travel whole)
-        complete = [z.clone() for z in zs[:-1]]
-        torch.save({'bounds': part.bounds, 'blocks': blocks, 'complete': complete,
-                    'dense': [g is None for g in part.give],
+        xb = part.new_buffer(5, 'cpu'); xb.fill_(float('nan'))
+        part.block(xb).copy_(x[part.r0:part.r1])               # the rank starts from its own rows only
+        zs = part.cheb_terms(xb, n_terms)
+        torch.save({'bounds': part.bounds, 'blocks': [part.block(z).clone() for z in zs],
+                    'halo': [z[part.n_local:].clone() for z in zs[:-1]], 'halo_ids': part.halo_ids.clone(),
+                    'peer_ptr': part.peer_ptr, 'sent_rows': part.sent_rows(), 'n_local': part.n_local,
                     'nnz': (part.L_int.nnz, part.L_ext.nnz, part.local_nnz)}, os.path.join(out_dir, 'r%d.pt' % rank))
         dist.barrier()
     finally:
@@ -237,13 +237,28 @@ def test_row_partitioned_recursion_matches_single_process(world, banded, tmp_pat
             got = o['blocks'][k][:, 0, :].double().numpy() + 1j * o['blocks'][k][:, 1, :].double().numpy()
             want = ref[k][bounds[r]:bounds[r + 1]]
             assert np.abs(got - want).max() <= 1e-5 * np.abs(ref[k]).max()
+        # after an order's exchange the halo holds the peers' rows of that order, in halo_ids order
+        ids = o['halo_ids'].long().numpy()
+        assert np.all(np.diff(ids) > 0) and not np.any((ids >= bounds[r]) & (ids < bounds[r + 1]))
+        assert o['peer_ptr'][0] == 0 and o['peer_ptr'][-1] == len(ids)
+        for k in range(n_terms - 1):
+            got = o['halo'][k][:, 0, :].double().numpy() + 1j * o['halo'][k][:, 1, :].double().numpy()
+            assert np.abs(got - ref[k][ids]).max() <= 1e-5 * np.abs(ref[k]).max()
         if banded:
-            assert not any(d for p, d in enumerate(o['dense']) if p != r)     # only boundary rows travelled
+            assert len(ids) <= 4 * 6 and o['sent_rows'] <= 4 * 6                  # only the band around the block travels
         else:
-            assert all(o['dense'])                                            # power-law graph: whole blocks
-            for k in range(n_terms - 1):
-                got = o['complete'][k][:, 0, :].double().numpy() + 1j * o['complete'][k][:, 1, :].double().numpy()
-                assert np.abs(got - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max()
+            assert len(ids) > 0.5 * (n - o['n_local'])                           # power-law graph: most remote rows
+    assert sum(o['sent_rows'] for o in outs) == sum(len(o['halo_ids']) for o in outs)
+
+
+def test_halo_plan_restatement_and_index_exchange_single_rank():
+    ci = torch.tensor([0, 5, 9, 2, 3, 9, 7, 1], dtype=torch.int32)
+    bounds = torch.tensor([0, 2, 6, 10], dtype=torch.int32)
+    ids, pp, cl = D.halo_plan_torch(ci, 10, 2, 6, bounds)                        # own columns 2..5
+    assert ids.tolist() == [0, 1, 7, 9] and pp.tolist() == [0, 2, 2, 4]
+    assert cl.tolist() == [4, 3, 7, 0, 1, 7, 6, 5]
+    assert D.exchange_index_lists([None], 0, 1) == [None]
+    assert D.row_partition_floats(10, 4, 3) == 3 * 10 * 8 and D.column_sharding_floats(100, 8, 3, 4) == 4 * 100 * 16 * 3 // 16
 
 
 def test_partition_bounds_balance_and_edge_cases():
@@ -277,7 +292,7 @@ def test_choose_strategy_follows_the_exchange_volume():
     column sharding on a graph without locality."""
     L, rp, ci, val = _graph(n=4000, e=60000)
     assert D.choose_strategy(rp, ci, 4000, 64, 3, 4) == 'cols'
-    assert D.choose_strategy(rp, ci, 4000, 64, 1, 4) == 'rows'          # no exchange at all
+    assert D.choose_strategy(rp, ci, 4000, 64, 0, 4) == 'rows'          # nothing to propagate, nothing to exchange
     assert D.choose_strategy(rp, ci, 4000, 6, 3, 4) == 'rows'           # columns do not split into float4 slices
     assert D.choose_strategy(rp, ci, 4000, 64, 3, 1) == 'rows'
     Lb, rpb, cib, valb = _banded_graph(n=4000, reach=6)

@@ -474,47 +474,129 @@ def test_magnetconv_edge_index_signature():
     assert conv.laplacian(ei, None, n) is not first
 
 
-def test_row_partition_operators_on_gpu():
-    """The HIP SpMM on the pieces the multi-GPU path uses (row blocks split into local-column and
-    remote-column CSRs, global column ids, outputs written into row blocks of full-height buffers).
-    Two ranks are emulated in one process; the exchange is a plain copy of row blocks."""
+def _emulated_partitions(L, n, world, lap, D, bounds=None):
+    """RowPartition objects of all ranks in one process: blocks cut from the full CSR, the need lists handed
+    over directly instead of through a process group."""
+    make = lambda rp, ci, v, nc: lap.MagneticLaplacian(rp, ci, v, nc)
+    bounds = bounds or D.partition_bounds(L.row_ptr, world)
+    parts = [D.RowPartition.from_global(L.row_ptr, L.col_idx, L.val, n, r, world, make, bounds=bounds) if world == 1 else
+             D.RowPartition(*D.slice_rows(L.row_ptr, L.col_idx, L.val, bounds[r], bounds[r + 1]), n, bounds, r, world, make,
+                            exchange_lists=lambda need, rank, world, group: [None] * world)
+             for r in range(world)]
+    for r, p in enumerate(parts):
+        p.give = [None if q == r else parts[q].need[r] for q in range(world)]
+    return parts
+
+
+def _emulated_exchange(parts, bufs, D):
+    """What RowPartition.exchange does over RCCL, as copies inside one process."""
+    for r, p in enumerate(parts):
+        for q, other in enumerate(parts):
+            if q == r or p.peer_ptr[q + 1] == p.peer_ptr[q]:
+                continue
+            rows = D.HipRowMover.gather(bufs[q], other.give[r])
+            bufs[r][p.n_local + p.peer_ptr[q]:p.n_local + p.peer_ptr[q + 1]] = rows
+
+
+@pytest.mark.parametrize('graph', ['powerlaw', 'banded'])
+def test_row_partition_operators_on_gpu(graph):
+    """The compact row partition on the GPU, three ranks emulated in one process: halo plan kernels against
+    their tensor restatement, the SpMM on the renumbered local-column / halo-column CSRs writing into compact
+    [own | halo] buffers, the packed exchange, against the single-GPU recursion."""
     _, lap, H, M, O = _mods()
     from magnet_amd import dist as D
     n, e, f, n_terms = 20000, 400000, 64, 4
-    src, dst = lap.powerlaw_edges(n, e, 21, device=DEV)
+    if graph == 'powerlaw':
+        src, dst = lap.powerlaw_edges(n, e, 21, device=DEV)
+    else:
+        g = torch.Generator().manual_seed(5)
+        src = torch.arange(n).repeat_interleave(4)
+        dst = (src + torch.randint(1, 40, (src.numel(),), generator=g)) % n
+        src, dst = src.to(DEV), dst.to(DEV)
     L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
-    make = lambda rp, ci, v, nc: lap.MagneticLaplacian(rp, ci, v, nc)
     world = 3
-    parts = [D.RowPartition(L.row_ptr, L.col_idx, L.val, n, r, world, make) for r in range(world)]
+    parts = _emulated_partitions(L, n, world, lap, D)
     assert sum(p.local_nnz for p in parts) == L.nnz
+    for r, p in enumerate(parts):
+        rp, ci, v = D.slice_rows(L.row_ptr, L.col_idx, L.val, p.r0, p.r1)
+        bt = torch.tensor(p.bounds, dtype=torch.int32, device=DEV)
+        ids, pp, cl = lap.halo_plan(ci, n, p.r0, p.r1, bt)
+        ids_t, pp_t, cl_t = D.halo_plan_torch(ci, n, p.r0, p.r1, bt)
+        assert torch.equal(ids, ids_t) and torch.equal(pp, pp_t) and torch.equal(cl, cl_t)
+        assert p.n_halo == ids.numel() and p.peer_ptr[r + 1] == p.peer_ptr[r]        # nothing to fetch from itself
+        assert p.L_int.nnz + p.L_ext.nnz == p.local_nnz
+        if graph == 'banded':
+            assert p.n_halo < 200                                                   # only the band around the block
     x = _rand_packed(n, f, 8)
     ref = [x, L.spmm(x)]
     for k in range(2, n_terms):
         ref.append(L.spmm(ref[k - 1], alpha=2.0, z1=ref[k - 2], beta1=-1.0))
-    zs = [[x] for _ in range(world)]
+    zs = []
+    for p in parts:
+        b = p.new_buffer(f, DEV); b.fill_(float('nan')); p.block(b).copy_(x[p.r0:p.r1])
+        zs.append([b])
+    _emulated_exchange(parts, [z[0] for z in zs], D)
     for k in range(1, n_terms):
-        new = [torch.full((n, 2, f), float('nan'), device=DEV) for _ in range(world)]
+        new = [torch.full((p.n_buf, 2, f), float('nan'), device=DEV) for p in parts]
         for r, p in enumerate(parts):
             if k == 1:
                 p.propagate(zs[r][0], new[r], 1.0)
             else:
                 p.propagate(zs[r][k - 1], new[r], 2.0, zs[r][k - 2], -1.0)
-        for r in range(world):                              # the exchange: every block to every rank
-            for s, p in enumerate(parts):
-                new[r][p.r0:p.r1] = new[s][p.r0:p.r1]
+        _emulated_exchange(parts, new, D)
         for r in range(world):
             zs[r].append(new[r])
     scale = float(ref[-1].abs().max())
-    for r in range(world):
-        assert float((zs[r][-1] - ref[-1]).abs().max()) <= 1e-5 * scale
+    for r, p in enumerate(parts):
+        assert float((p.block(zs[r][-1]) - ref[-1][p.r0:p.r1]).abs().max()) <= 1e-5 * scale
+        assert torch.equal(zs[r][-2][p.n_local:], ref[-2][p.halo_ids.long()]) or \
+            float((zs[r][-2][p.n_local:] - ref[-2][p.halo_ids.long()]).abs().max()) <= 1e-5 * scale
     # the bench's distributed layer with a single rank equals the single-GPU layer
-    layer = D.RowPartitionedConv(L, f, f, 2, 0, 1, torch.device(DEV))
+    layer = D.RowPartitionedConv(L, [0, n], f, f, 2, 0, 1, torch.device(DEV))
     out = layer.step()
     conv = M.ChebConv(f, f, 2, H.cheb_poly_sparse(L, 2), None).to(DEV)
     with torch.no_grad():
         conv.weight.copy_(layer.weight); conv.bias.copy_(layer.bias)
         want = conv.forward_packed(layer.x)
     assert float((out - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('case', ['unweighted', 'weighted', 'lambda3'])
+def test_row_blocks_built_per_rank_stack_to_the_full_laplacian(case):
+    """Every rank builds only its own row block from the edges incident to it (mh_lap_block_*); the blocks of
+    a partition, stacked, equal the single-GPU CSR bit for bit (structure and values)."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd import dist as D
+    n, e, world = 30000, 500000, 4
+    src, dst = lap.powerlaw_edges(n, e, 33, device=DEV)
+    w = None
+    if case == 'weighted':
+        w = (torch.rand(e, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 3 + 0.25)
+    lam = 3.0 if case == 'lambda3' else 2.0
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.2, edge_weight=w, max_eigen=lam)
+    deg = torch.bincount(src.long(), minlength=n) + torch.bincount(dst.long(), minlength=n)
+    bounds = D.bounds_from_degrees(deg, world)
+    assert bounds[0] == 0 and bounds[-1] == n
+    builds = []
+    for r in range(world):
+        r0, r1 = bounds[r], bounds[r + 1]
+        fm, bm = (src >= r0) & (src < r1), (dst >= r0) & (dst < r1)
+        fwd = (src[fm], dst[fm]) + ((w[fm],) if w is not None else ())
+        bwd = (src[bm], dst[bm]) + ((w[bm],) if w is not None else ())
+        builds.append(lap.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam))
+    dinv = torch.cat([b.dinv_block for b in builds])
+    assert torch.equal(dinv, L.dinv)
+    blocks = [b.finish(dinv, 0.2) for b in builds]
+    assert sum(b.nnz for b in blocks) == L.nnz
+    for r, blk in enumerate(blocks):
+        rp, ci, v = D.slice_rows(L.row_ptr, L.col_idx, L.val, bounds[r], bounds[r + 1])
+        assert torch.equal(blk.row_ptr, rp) and torch.equal(blk.col_idx, ci) and torch.equal(blk.val, v)
+    # single rank through the distributed entry point (no process group needed)
+    one, b1 = D.build_row_block(lambda: iter([(src, dst) + ((w,) if w is not None else ())]), n, 0, 1, q=0.2, max_eigen=lam)
+    assert b1 == [0, n] and torch.equal(one.row_ptr, L.row_ptr) and torch.equal(one.col_idx, L.col_idx) and torch.equal(one.val, L.val)
+    # an edge that does not belong to the block is refused
+    with pytest.raises(lap.MagnetHipError):
+        lap.LaplacianBlockBuild((src[:10], dst[:10]), (src[:0], dst[:0]), n, n - 5, n)
 
 
 def test_training_epochs_follow_the_oracle():
