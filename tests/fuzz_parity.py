@@ -216,7 +216,8 @@ def net_case(rng, row, col, n, q, w, L, S):
     Ts = O.cheb_poly_sparse(S, K)
     if sum(t.nnz for t in Ts) > 3_000_000:
         return 'net skipped (T_k too dense for the CPU oracle)'
-    Lr, Li = O.laplacian_lists(Ts)
+    # the oracle runs in float64 on the float32 Laplacian values: the exact result a float32 implementation is held to
+    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(S.astype(np.complex128), K), np.float64)
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
     torch.manual_seed(int(rng.integers(0, 2 ** 31)))
     cls = M.ChebNet_Edge if edge else M.ChebNet
@@ -225,31 +226,42 @@ def net_case(rng, row, col, n, q, w, L, S):
         for m in net.Chebs:
             if hasattr(m, 'bias'):
                 m.bias.uniform_(-0.3, 0.3)
-    state = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    state = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     Xr = torch.randn(n, cin, generator=g); Xi = torch.randn(n, cin, generator=g)
+    if act:
+        # A complex ReLU whose input real part is within float32 rounding of zero may legitimately open in one
+        # computation and close in the other.  That is decided from the pre-activations themselves (float64), never
+        # from the size of the final error.
+        real, imag, j = Xr.double(), Xi.double(), 0
+        with torch.no_grad():
+            for li in range(layer):
+                real, imag = O.cheb_conv(Lr, Li, state['Chebs.%d.weight' % j], state['Chebs.%d.bias' % j], real, imag)
+                j += 1
+                if not (edge and layer == 1 and li == 0):
+                    if bool((real.abs() < 2e-5 * max(float(real.abs().max()), 1e-30)).any()):
+                        return 'net skipped (a pre-activation real part within rounding of zero decides a gate)'
+                    real, imag = O.complex_relu(real, imag)
+                    j += 1
     if edge:
         m_pairs = int(rng.integers(1, 400))
         pairs = torch.from_numpy(rng.integers(0, n, (m_pairs, 2)))
         y = torch.from_numpy(rng.integers(0, ncls, m_pairs))
         out = net(Xr.cuda(), Xi.cuda(), pairs.cuda())
-        ref = O.chebnet_edge_forward(state, Lr, Li, Xr, Xi, pairs, layer, act)
+        ref = O.chebnet_edge_forward(state, Lr, Li, Xr.double(), Xi.double(), pairs, layer, act)
         loss, rloss = torch.nn.functional.nll_loss(out, y.cuda()), torch.nn.functional.nll_loss(ref, y)
     else:
         y = torch.from_numpy(rng.integers(0, ncls, (1, n)))
         out = net(Xr.cuda(), Xi.cuda())
-        ref = O.chebnet_forward(state, Lr, Li, Xr, Xi, layer, act)
+        ref = O.chebnet_forward(state, Lr, Li, Xr.double(), Xi.double(), layer, act)
         loss, rloss = torch.nn.NLLLoss()(out, y.cuda()), torch.nn.NLLLoss()(ref, y)
-    # a ReLU gate decided within rounding makes the two computations legitimately differ: detect and skip
-    if act and float((out.detach().cpu() - ref.detach()).abs().max()) > 1e-3 * max(float(ref.detach().abs().max()), 1e-30):
-        return 'net skipped (gate decided within rounding)'
-    close(out.detach().cpu(), ref.detach(), 5e-5, 'net out')
+    close(out.detach().cpu().double(), ref.detach(), 1e-5, 'net out')
     loss.backward(); rloss.backward()
     for k, p in net.named_parameters():
         gr = state[k].grad
         scale = max(float(gr.abs().max()), 1e-6)
-        if float((p.grad.cpu() - gr).abs().max()) > 2e-4 * scale + 1e-7:
+        if float((p.grad.cpu().double() - gr).abs().max()) > 1e-5 * scale + 1e-7:
             raise AssertionError('net grad %s: err %.3e scale %.3e (K=%d layer=%d F=%d cin=%d act=%d edge=%d)' % (
-                k, float((p.grad.cpu() - gr).abs().max()), scale, K, layer, F, cin, act, edge))
+                k, float((p.grad.cpu().double() - gr).abs().max()), scale, K, layer, F, cin, act, edge))
     return 'net ok K=%d layer=%d F=%d cin=%d act=%d edge=%d' % (K, layer, F, cin, act, edge)
 
 

@@ -37,10 +37,11 @@ def _import_reference():
     return hermitian_decomp_sparse, cheb_poly_sparse, ChebConv, ChebNet, ChebNet_Edge
 
 
-def to_coo_lists(L):
-    """scipy list -> (L_real, L_imag) torch COO lists, as src/sparse_Magnet.py:55-62,108-112."""
+def to_coo_lists(L, dtype=np.float32):
+    """scipy list -> (L_real, L_imag) torch COO lists, as src/sparse_Magnet.py:55-62,108-112
+    (dtype float64 only for the exact-arithmetic companions of a case)."""
     def conv(mx):
-        mx = mx.tocoo().astype(np.float32)
+        mx = mx.tocoo().astype(dtype)
         idx = torch.from_numpy(np.vstack((mx.row, mx.col)).astype(np.int64))
         return torch.sparse_coo_tensor(idx, torch.from_numpy(mx.data), torch.Size(mx.shape))
     return [conv(l.real) for l in L], [conv(l.imag) for l in L]
@@ -374,6 +375,26 @@ def config_cases(ref_h, ref_c, ChebNet):
             out[name + '/state/' + k] = v.numpy().copy()
         for k, p in net.named_parameters():
             out[name + '/grad/' + k] = p.grad.numpy().copy()
+        # The same step in float64 from the same float32 Laplacian values, weights and inputs: the reference's own
+        # classes (polynomials of the matrix, four spmm per order) with every tensor a double.  It is the exact
+        # result both the reference's float32 run above and a float32 implementation under test approximate.
+        L64 = ref_c(L[1].astype(np.complex128), K)
+        Lr64, Li64 = to_coo_lists(L64, np.float64)
+        net64 = ChebNet(X.size(1), Lr64, Li64, num_filter=16, K=K, label_dim=int(y.max()) + 1, activation=True, layer=2,
+                        dropout=0.0).double()
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        Xr64 = X.double().clone().requires_grad_(True); Xi64 = X.double().clone().requires_grad_(True)
+        preds64 = net64(Xr64, Xi64)
+        loss64 = torch.nn.NLLLoss()(preds64[:, :, train], torch.from_numpy(y[None])[:, train])
+        loss64.backward()
+        out[name + '/truth/preds'] = preds64.detach().numpy(); out[name + '/truth/loss'] = np.array(loss64.item())
+        out[name + '/truth/dXr'] = Xr64.grad.numpy().copy(); out[name + '/truth/dXi'] = Xi64.grad.numpy().copy()
+        for k, p in net64.named_parameters():
+            out[name + '/truth/grad/' + k] = p.grad.numpy().copy()
+        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        print('  float32 reference vs float64: preds %.2e, loss %.2e, grads %s' % (
+            rel(out[name + '/preds'], out[name + '/truth/preds']), abs(loss.item() - loss64.item()) / abs(loss64.item()),
+            ' '.join('%.1e' % rel(out[name + '/grad/' + k], out[name + '/truth/grad/' + k]) for k, _ in net.named_parameters())))
         print('config case %s: n=%d E=%d nnz(T_k)=%s loss=%.6f' % (name, n, len(row), [l.nnz for l in L], loss.item()))
     out['names'] = np.array(sorted(graphs))
     np.savez_compressed(os.path.join(HERE, 'config_cases.npz'), **out)
