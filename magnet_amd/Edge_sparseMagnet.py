@@ -18,7 +18,7 @@ import torch.optim as optim
 
 from . import data as D
 from .layer.sparse_magnet import ChebNet_Edge
-from .utils.edge_data import in_out_degree, generate_dataset_3class, link_prediction_evaluation, acc
+from .utils.edge_data import in_out_degree, generate_dataset_3class, link_prediction_evaluation, acc, split_cache_prefix
 from .utils.preprocess import to_edge_dataset_sparse
 from .utils.save_settings import write_log
 
@@ -85,9 +85,7 @@ def main(args):
     data = load_graph(args)
     edge_index = data.edge_index
     size = int(torch.max(edge_index).item()) + 1
-    parts = args.dataset.split('/')
-    subset = parts[1] if len(parts) > 1 else ''
-    save_file = os.path.join(args.log_root, 'splits', args.dataset.replace('/', '_')) + '/' + subset
+    save_file = split_cache_prefix(args.data_path, args.dataset, args.log_root, args.task, args.num_class_link, args.split_prob)
     datasets = generate_dataset_3class(edge_index, size, save_file, splits=args.splits, probs=args.split_prob,
                                        task=args.task, label_dim=args.num_class_link)
     results = np.zeros((args.splits, 4)) if args.task != 2 else np.zeros((args.splits, 4, 5))

@@ -130,6 +130,27 @@ def undirected_label2directed_label(adj, edge_pairs, task):
     return new_edge_pairs[labels >= 0], labels[labels >= 0]
 
 
+def split_cache_file(save_path, task, label_dim, probs):
+    """Name of a link-split cache as the reference forms it (src/utils/edge_data.py:164)."""
+    return save_path + 'task' + str(task) + 'dim' + str(label_dim) + 'prob' + str(int(probs[0] * 100)) + '_' + \
+        str(int(probs[1] * 100)) + '.pk'
+
+
+def split_cache_prefix(data_path, dataset, log_root, task, label_dim, probs):
+    """Where the link driver keeps its splits.  The reference looks under the dataset folder,
+    data_path + dataset + '/' + subset (src/Edge_sparseMagnet.py:110), which is where its shipped caches live
+    (citeseer/task1dim2prob15_5.pk, WebKB/Cornell/Cornelltask2dim2prob15_5.pk ...): a cache found there is
+    used as it is.  Splits generated here (the reference delegates the draw to stellargraph's EdgeSplitter;
+    ours comes from a seeded numpy generator) are written under log_root instead, so that they can never be
+    mistaken for, or overwrite, the reference's."""
+    parts = dataset.split('/')
+    subset = parts[1] if len(parts) > 1 else ''
+    reference_prefix = data_path + dataset + '/' + subset
+    if os.path.exists(split_cache_file(reference_prefix, task, label_dim, probs)):
+        return reference_prefix
+    return os.path.join(log_root, 'splits', dataset.replace('/', '_')) + '/' + subset
+
+
 def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15, 0.05), task=2, label_dim=2):
     """{split: {'graph': LongTensor [2, E_obs], 'undirected': ndarray, 'train' | 'validate' | 'test':
     {'pairs': int [M, 2], 'label': int32 [M]}}} — the layout of reference :221-239, cached under the
@@ -138,8 +159,7 @@ def generate_dataset_3class(edge_index, size, save_path, splits=10, probs=(0.15,
     (utils.inert_pickle), never unpickled."""
     import pickle as pk
     import scipy.sparse as sp
-    save_file = save_path + 'task' + str(task) + 'dim' + str(label_dim) + 'prob' + str(int(probs[0] * 100)) + '_' + \
-        str(int(probs[1] * 100)) + '.pk'
+    save_file = split_cache_file(save_path, task, label_dim, probs)
     if os.path.exists(save_file):
         from .inert_pickle import load_inert, to_numpy
         with open(save_file, 'rb') as f:

@@ -400,7 +400,88 @@ def config_cases(ref_h, ref_c, ChebNet):
     np.savez_compressed(os.path.join(HERE, 'config_cases.npz'), **out)
 
 
+def link_split_cases(ref_h, ref_c, ChebNet_Edge):
+    """BASELINE configuration 3 on the reference's OWN artefacts: split 0 of the link-split caches it ships
+    (written by src/utils/edge_data.py:259-263) — citeseer/task1dim2prob15_5.pk (existence) and
+    cora_ml/task2dim2prob15_5.pk (direction) — read by walking their pickle opcodes (nothing in them is
+    executed), then one training step of the reference's ChebNet_Edge as src/Edge_sparseMagnet.py:121-186
+    runs it: Laplacian of the split's observed graph (q = 0.1, K = 2), the driver's degree features
+    (in_out_degree called with the [2, E] tensor), 16 filters, 2 layers, complex ReLU, dropout 0 (parity),
+    NLL loss on the split's training pairs, backward; plus the evaluation forward on the validation pairs,
+    and the same step in float64."""
+    from utils.edge_data import in_out_degree
+    sys.path.insert(0, os.path.join(HERE, '..', '..'))
+    from magnet_amd.utils.inert_pickle import load_inert, to_numpy
+    c = np.load(os.path.join(REF, 'dataset/data/tmp/citeseer_npz/citeseer_npz.npz'), allow_pickle=False)
+    n_citeseer = int(max(c['adj_indices'].max() + 1, len(c['adj_indptr']) - 1))
+    out = {}
+    names = []
+    for name, rel, task, size in [('citeseer_task1', 'citeseer/task1dim2prob15_5.pk', 1, n_citeseer),
+                                  ('cora_ml_task2', 'cora_ml/task2dim2prob15_5.pk', 2, None)]:
+        with open(os.path.join(REF, 'dataset/data/tmp', rel), 'rb') as f:
+            splits = to_numpy(load_inert(f.read()))
+        d = splits[0]
+        edges = d['graph'].long()
+        parts = {k: (np.asarray(d[k]['pairs']).astype(np.int64), np.asarray(d[k]['label']).astype(np.int64))
+                 for k in ('train', 'validate', 'test')}
+        if size is None:
+            # cora_ml.npz is not shipped: the driver's size = max(edge_index) + 1 of the full graph is bounded
+            # below by every node id the split mentions; Cora-ML has 2 995 nodes
+            size = max(2995, int(edges.max()) + 1, max(int(p.max()) + 1 for p, _ in parts.values()))
+        names.append(name)
+        L = ref_c(ref_h(edges[0], edges[1], size, 0.1, True, True, 2.0, False, None), 2)
+        Lr, Li = to_coo_lists(L)
+        X = in_out_degree(edges, size)
+        torch.manual_seed(500 + task)
+        net = ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0)
+        for m in net.Chebs:
+            if hasattr(m, 'bias'):
+                with torch.no_grad():
+                    m.bias.uniform_(-0.3, 0.3)
+        tp, tl = torch.from_numpy(parts['train'][0]), torch.from_numpy(parts['train'][1])
+        vp, vl = torch.from_numpy(parts['validate'][0]), torch.from_numpy(parts['validate'][1])
+        o = net(X.clone(), X.clone(), tp)
+        loss = torch.nn.functional.nll_loss(o, tl)
+        loss.backward()
+        with torch.no_grad():
+            ov = net(X.clone(), X.clone(), vp)
+            vloss = torch.nn.functional.nll_loss(ov, vl)
+        L64 = ref_c(L[1].astype(np.complex128), 2)
+        Lr64, Li64 = to_coo_lists(L64, np.float64)
+        net64 = ChebNet_Edge(X.size(-1), Lr64, Li64, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0).double()
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        o64 = net64(X.double(), X.double(), tp)
+        loss64 = torch.nn.functional.nll_loss(o64, tl)
+        loss64.backward()
+        pre = name + '/'
+        out[pre + 'graph'] = edges.numpy().astype(np.int32); out[pre + 'size'] = np.array(size)
+        for k, (p, l) in parts.items():
+            out[pre + k + '/pairs'] = p.astype(np.int32); out[pre + k + '/label'] = l.astype(np.int8)
+        out[pre + 'X'] = X.numpy()
+        Lc = L[1].tocsr(); Lc.sort_indices()
+        out[pre + 'indptr'] = Lc.indptr.astype(np.int32); out[pre + 'indices'] = Lc.indices.astype(np.int32)
+        out[pre + 'data'] = Lc.data.astype(np.complex64)
+        out[pre + 'out'] = o.detach().numpy(); out[pre + 'loss'] = np.array(loss.item())
+        out[pre + 'val_out'] = ov.numpy(); out[pre + 'val_loss'] = np.array(vloss.item())
+        out[pre + 'truth/out'] = o64.detach().numpy(); out[pre + 'truth/loss'] = np.array(loss64.item())
+        for k, v in net.state_dict().items():
+            out[pre + 'state/' + k] = v.numpy().copy()
+        for k, p in net.named_parameters():
+            out[pre + 'grad/' + k] = p.grad.numpy().copy()
+        for k, p in net64.named_parameters():
+            out[pre + 'truth/grad/' + k] = p.grad.numpy().copy()
+        print('link split case %s: size=%d E_obs=%d nnz=%d pairs train/val/test=%d/%d/%d loss=%.6f (float64 %.6f) nonzero X: %d' % (
+            name, size, edges.size(1), Lc.nnz, len(parts['train'][0]), len(parts['validate'][0]), len(parts['test'][0]),
+            loss.item(), loss64.item(), int((X != 0).sum())))
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'link_split_cases.npz'), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'linksplits':   # only the cases on the reference's shipped link splits
+        ref_h, ref_c, ChebConv, ChebNet, ChebNet_Edge = _import_reference()
+        link_split_cases(ref_h, ref_c, ChebNet_Edge)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'splits':
         _import_reference()
         label_cases()
@@ -418,5 +499,6 @@ if __name__ == '__main__':
     net_cases(ref_h, ref_c, ChebNet, ChebNet_Edge)
     citeseer_case(ref_h, ref_c, ChebNet_Edge)
     config_cases(ref_h, ref_c, ChebNet)
+    link_split_cases(ref_h, ref_c, ChebNet_Edge)
     label_cases()
     split_cases()

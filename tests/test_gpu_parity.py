@@ -470,6 +470,59 @@ def test_citeseer_link_prediction_step():
         assert_close(p.grad.cpu().numpy(), g['grad/' + k], what='grad ' + k)
 
 
+LINKS = load_golden('link_split_cases.npz')
+
+
+@pytest.mark.parametrize('mode', ['basis', 'reference_lists'])
+@pytest.mark.parametrize('name', [str(s) for s in LINKS['names']])
+def test_reference_link_splits_step(name, mode):
+    """BASELINE configuration 3 on the reference's own artefacts: split 0 of the link-split caches it ships
+    (citeseer/task1dim2prob15_5.pk: existence; cora_ml/task2dim2prob15_5.pk: direction), K = 2, q = 0.1,
+    16 filters — the observed graph's Laplacian (structure exact), the driver's degree features, one training
+    step of ChebNet_Edge on the split's training pairs (outputs, loss, every parameter gradient) and the
+    evaluation forward on its validation pairs, against the reference's float32 run and its float64 companion."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd.utils.edge_data import in_out_degree
+    g, pre = LINKS, name + '/'
+    size = int(g[pre + 'size'])
+    edges = torch.from_numpy(g[pre + 'graph'].astype(np.int64)).to(DEV)
+    L = H.hermitian_decomp_sparse_device(edges[0], edges[1], size, 0.1)
+    Ls = L.to_scipy()
+    assert np.array_equal(Ls.indptr, g[pre + 'indptr']) and np.array_equal(Ls.indices, g[pre + 'indices'])
+    assert_close(Ls.data.real, g[pre + 'data'].real); assert_close(Ls.data.imag, g[pre + 'data'].imag)
+    X = in_out_degree(edges, size).to(DEV)
+    assert np.array_equal(X.cpu().numpy(), g[pre + 'X'])
+    if mode == 'basis':
+        Lr, Li = H.cheb_poly_sparse(L, 2), None
+    else:
+        Lo = sp.csr_matrix((g[pre + 'data'], g[pre + 'indices'], g[pre + 'indptr']), shape=(size, size))
+        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, 2))
+        Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
+    state = {k[len(pre) + 6:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(pre + 'state/')}
+    net = M.ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0).to(DEV)
+    net.load_state_dict(state)
+    tp = torch.from_numpy(g[pre + 'train/pairs'].astype(np.int64)).to(DEV)
+    tl = torch.from_numpy(g[pre + 'train/label'].astype(np.int64)).to(DEV)
+    out = net(X.clone(), X.clone(), tp)
+    loss = torch.nn.functional.nll_loss(out, tl)
+    loss.backward()
+    c = lambda x: x.detach().cpu().numpy()
+    assert_close(c(out), g[pre + 'out'], what='out')
+    assert np.abs(c(out) - g[pre + 'truth/out']).max() <= 1e-5 * np.abs(g[pre + 'truth/out']).max()
+    assert abs(loss.item() - float(g[pre + 'loss'])) <= 1e-5 * float(g[pre + 'loss'])
+    assert abs(loss.item() - float(g[pre + 'truth/loss'])) <= 1e-5 * float(g[pre + 'truth/loss'])
+    for k, p in net.named_parameters():
+        assert_close(c(p.grad), g[pre + 'grad/' + k], what='grad ' + k)
+        t = g[pre + 'truth/grad/' + k]
+        assert np.abs(c(p.grad) - t).max() <= 1e-5 * np.abs(t).max() + 1e-9, 'grad %s vs float64' % k
+    net.eval()
+    with torch.no_grad():
+        ov = net(X.clone(), X.clone(), torch.from_numpy(g[pre + 'validate/pairs'].astype(np.int64)).to(DEV))
+        vloss = torch.nn.functional.nll_loss(ov, torch.from_numpy(g[pre + 'validate/label'].astype(np.int64)).to(DEV))
+    assert_close(c(ov), g[pre + 'val_out'], what='validation out')
+    assert abs(vloss.item() - float(g[pre + 'val_loss'])) <= 1e-5 * float(g[pre + 'val_loss'])
+
+
 def test_magnetconv_edge_index_signature():
     _, lap, H, M, O = _mods()
     row, col, n, _ = _telegram(0.25, False)
@@ -790,9 +843,22 @@ def test_link_driver_runs_all_tasks(tmp_path):
         res = drv.run(['-D', '--dataset', 'syn/cyclic', '--task', str(task), '--num_class_link', str(ncls), '--q', '0.1',
                        '--K', '2', '-a', '--num_filter', '8', '--splits', '1', '--log_root', root, '--data_path', root])
         assert res.shape[0] == 1 and np.isfinite(res).all()
+    # a split cache at the place the reference keeps its own (data_path + dataset + '/' + subset + 'task..') is what the
+    # driver trains on: nothing is generated, nothing is written under log_root for that task
+    import glob, os
+    from magnet_amd.utils.edge_data import generate_dataset_3class, in_out_degree, split_cache_file
+    from magnet_amd import data as D
+    assert len(glob.glob(root + 'splits/**/*task1dim2*.pk', recursive=True)) == 1          # generated by the run above
+    root2 = str(tmp_path / 'second') + '/'
+    other = torch.randint(0, 2500, (2, 20000), generator=torch.Generator().manual_seed(9))      # not the DSBM the driver loads
+    generate_dataset_3class(other, 2500, root2 + 'syn/cyclic/cyclic', splits=1, task=1, label_dim=2)
+    assert os.path.isfile(split_cache_file(root2 + 'syn/cyclic/cyclic', 1, 2, [0.15, 0.05]))
+    res = drv.run(['-D', '--dataset', 'syn/cyclic', '--task', '1', '--num_class_link', '2', '--q', '0.1', '--K', '2', '-a',
+                   '--num_filter', '8', '--splits', '1', '--log_root', root2, '--data_path', root2])
+    assert res.shape[0] == 1 and np.isfinite(res).all()
+    assert glob.glob(root2 + 'splits/**/*.pk', recursive=True) == []
     # a real run on the CiteSeer graph of the golden fixture: direction task, true degree features
     _, lap, H, M, O = _mods()
-    from magnet_amd.utils.edge_data import generate_dataset_3class, in_out_degree
     from magnet_amd.utils.preprocess import to_edge_dataset_sparse
     from magnet_amd.train import link_epoch
     g = load_golden('citeseer_link_case.npz')

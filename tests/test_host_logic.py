@@ -108,6 +108,39 @@ def test_link_split_generation(tmp_path):
     assert set(np.unique(l)) <= {0, 1} and abs(int((l == 0).sum()) - int((l == 1).sum())) <= 1
 
 
+def test_link_driver_finds_split_caches_where_the_reference_keeps_them(tmp_path):
+    """The link driver's split cache is looked up at data_path + dataset + '/' + subset (reference
+    src/Edge_sparseMagnet.py:110), the place of the caches the reference ships; a cache found there is read
+    without unpickling and used as it is, and only splits generated here go under log_root."""
+    import os
+    from magnet_amd.utils.edge_data import generate_dataset_3class, split_cache_prefix, split_cache_file
+    data_path, log_root = str(tmp_path / 'data') + '/', str(tmp_path / 'logs') + '/'
+    for dataset, shipped_name in (('citeseer/', 'citeseer/task1dim2prob15_5.pk'),
+                                  ('WebKB/Cornell', 'WebKB/Cornell/Cornelltask1dim2prob15_5.pk')):
+        assert split_cache_prefix(data_path, dataset, log_root, 1, 2, [0.15, 0.05]).startswith(log_root)     # nothing shipped yet
+        # a cache in the reference's format at the reference's location
+        g = torch.Generator().manual_seed(0)
+        ei = torch.randint(0, 60, (2, 400), generator=g)
+        made = generate_dataset_3class(ei, 60, str(tmp_path / 'made') + '/', splits=10, task=1, label_dim=2)
+        os.makedirs(os.path.dirname(data_path + shipped_name), exist_ok=True)
+        os.replace(split_cache_file(str(tmp_path / 'made') + '/', 1, 2, [0.15, 0.05]), data_path + shipped_name)
+        prefix = split_cache_prefix(data_path, dataset, log_root, 1, 2, [0.15, 0.05])
+        assert split_cache_file(prefix, 1, 2, [0.15, 0.05]) == data_path + dataset + ('/' if dataset.endswith('/') else '/Cornell') + \
+            'task1dim2prob15_5.pk'
+        assert os.path.samefile(split_cache_file(prefix, 1, 2, [0.15, 0.05]), data_path + shipped_name)
+        # the driver's call: a different graph is passed, the cache wins and is returned as stored
+        used = generate_dataset_3class(torch.zeros(2, 3, dtype=torch.long), 60, prefix, splits=10, probs=[0.15, 0.05], task=1, label_dim=2)
+        assert torch.equal(used[3]['graph'], made[3]['graph']) and np.array_equal(used[3]['train']['pairs'], made[3]['train']['pairs'])
+        assert split_cache_prefix(data_path, dataset, log_root, 2, 2, [0.15, 0.05]).startswith(log_root)     # other task: not shipped
+    # the reference's own shipped cache through the same path (build container only)
+    ref_root = '/root/reference/dataset/data/tmp/'
+    if os.path.isfile(ref_root + 'citeseer/task1dim2prob15_5.pk'):
+        prefix = split_cache_prefix(ref_root, 'citeseer/', log_root, 1, 2, [0.15, 0.05])
+        assert prefix == ref_root + 'citeseer//'
+        c = generate_dataset_3class(None, 0, prefix, splits=10, probs=[0.15, 0.05], task=1, label_dim=2)
+        assert tuple(c[0]['graph'].shape) == (2, 3763) and c[0]['train']['pairs'].shape == (7345, 2)
+
+
 def test_dsbm_meta_graphs():
     """The three meta-graph families of the reference's DSBM generators: which cluster pairs are
     linked and which way their edges point."""
