@@ -233,6 +233,7 @@ def epoch_time(rank, world, dev, multi):
     if multi:
         sh.cache_input_propagation = True
     ms_cached = timed()
+    ChebConv.cache_input_propagation = False       # back to the default
     return {'ms': ms, 'ms_with_cached_input_propagation': ms_cached, 'n_gpus': world, 'nnz': lap.nnz,
             'config': 'config 4: power-law digraph N=2M E=40M, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
                       'train fwd+bwd+Adam + eval fwd' + (', ShardedChebNet' if multi else '')}

@@ -97,6 +97,8 @@ def main(args):
         X_real = X_img.clone()
         model = ChebNet_Edge(X_real.size(-1), L, None, K=args.K, label_dim=args.num_class_link, layer=args.layer,
                              activation=args.activation, num_filter=args.num_filter, dropout=args.dropout).to(device)
+        # the driver owns X_real / X_img and never writes them in place: keep the first layer's T_k(L) X across epochs
+        model.Chebs[0].cache_input_propagation = True
         opt = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.l2)
         y = {k: torch.from_numpy(datasets[i][k]['label']).long().to(device) for k in ('train', 'validate', 'test')}
         idx = {k: torch.from_numpy(np.asarray(datasets[i][k]['pairs'])).long().to(device) for k in ('train', 'validate', 'test')}

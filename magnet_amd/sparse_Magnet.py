@@ -178,6 +178,8 @@ def main(args):
         log_str_full = ''
         model = ChebNet(X_real.size(-1), L, None, K=args.K, label_dim=cluster_dim, layer=args.layer,
                         activation=args.activation, num_filter=args.num_filter, dropout=args.dropout).to(device)
+        # the driver owns X_real / X_img and never writes them in place: keep the first layer's T_k(L) X across epochs
+        model.Chebs[0].cache_input_propagation = True
         opt = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.l2, capturable=args.hip_graph)
         as_index = lambda m: torch.from_numpy(m).to(device).nonzero().squeeze(1) if m.dtype == np.bool_ \
             else torch.from_numpy(m).to(device).long()

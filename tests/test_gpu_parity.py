@@ -1104,9 +1104,11 @@ def test_cached_input_propagation_is_transparent():
     net = M.ChebNet(6, H.cheb_poly_sparse(L, 2), None, num_filter=8, K=2, label_dim=4, activation=True, layer=2).to(DEV)
     g = torch.Generator().manual_seed(4)
     X = torch.randn(n, 6, generator=g).to(DEV); Xi = torch.randn(n, 6, generator=g).to(DEV)
+    assert M.ChebConv.cache_input_propagation is False          # opt-in: the reference recomputes on every forward
+    assert getattr(net.Chebs[0], '_input_cache', None) is None
     try:
-        M.ChebConv.cache_input_propagation = False
         plain = net(X, Xi).detach().clone()
+        assert getattr(net.Chebs[0], '_input_cache', None) is None
         M.ChebConv.cache_input_propagation = True
         a = net(X, Xi).detach().clone()           # fills the cache
         b = net(X, Xi).detach().clone()           # served from it
@@ -1130,7 +1132,26 @@ def test_cached_input_propagation_is_transparent():
         for p, gc in zip(net.parameters(), g_cached):
             assert_close(p.grad.cpu().numpy(), gc.cpu().numpy(), rel=1e-5)
     finally:
-        M.ChebConv.cache_input_propagation = True
+        M.ChebConv.cache_input_propagation = False
+    # the caches of converted Laplacians and pair lists hold their keys weakly: nothing outlives its tensor
+    import gc
+    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(O.hermitian_decomp_sparse(row, col, n, 0.25), 1))
+    Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
+    before = len(M._COO_CACHE)
+    conv = M.ChebConv(6, 4, 1, Lr, Li).to(DEV)
+    conv((X, Xi))
+    assert len(M._COO_CACHE) == before + 2
+    del conv, Lr, Li
+    gc.collect()
+    assert len(M._COO_CACHE) == before
+    pairs = torch.randint(0, n, (50, 2), device=DEV)
+    enet = M.ChebNet_Edge(6, H.cheb_poly_sparse(L, 1), None, num_filter=4, K=1, label_dim=2, layer=1).to(DEV)
+    nb = len(M._PAIR_CACHE)
+    enet(X, Xi, pairs); enet(X, Xi, pairs)
+    assert len(M._PAIR_CACHE) == nb + 1
+    del pairs
+    gc.collect()
+    assert len(M._PAIR_CACHE) == nb
 
 
 def test_trunk_hand_over_of_order_blocks():
