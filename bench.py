@@ -51,6 +51,8 @@ def parse_args():
                    help='apply a random vertex relabelling (seed 99) to the generated graph: the locality-free stress variant')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-epoch', action='store_true', help='skip the secondary epoch-time measurement')
+    p.add_argument('--epoch-nodes', type=int, default=2_000_000, help='graph of the secondary epoch measurement (config 4)')
+    p.add_argument('--epoch-edges', type=int, default=40_000_000)
     p.add_argument('--cpu-sample-nodes', type=int, default=250_000)
     p.add_argument('--cpu-sample-edges', type=int, default=5_000_000)
     return p.parse_args()
@@ -172,7 +174,7 @@ def cpu_baseline(args):
     }
 
 
-def epoch_time(rank, world, dev, multi):
+def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000):
     """Secondary metric: one training epoch (train forward + backward + Adam, then an evaluation
     forward: reference src/sparse_Magnet.py:143-176) of a 2-layer ChebNet, 128 -> 128 -> 128 filters,
     K = 2, q = 0.25, complex ReLU, 5 classes, on BASELINE.json config 4 (power-law digraph, 2M nodes /
@@ -182,7 +184,7 @@ def epoch_time(rank, world, dev, multi):
     from magnet_amd.layer.sparse_magnet import ChebNet
     from magnet_amd.utils.hermitian import ChebBasis
     from magnet_amd.train import node_epoch
-    n, e, f, K, ncls = 2_000_000, 40_000_000, 128, 2, 5
+    f, K, ncls = 128, 2, 5
     src, dst = powerlaw_edges(n, e, 42, device=dev)
     lap = build_magnetic_laplacian(src, dst, n, q=0.25)
     del src, dst
@@ -223,7 +225,8 @@ def epoch_time(rank, world, dev, multi):
         dt = time.perf_counter() - t0
         if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            from magnet_amd.dist import all_reduce
+            all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         return dt / iters * 1e3
 
@@ -235,8 +238,8 @@ def epoch_time(rank, world, dev, multi):
     ms_cached = timed()
     ChebConv.cache_input_propagation = False       # back to the default
     return {'ms': ms, 'ms_with_cached_input_propagation': ms_cached, 'n_gpus': world, 'nnz': lap.nnz,
-            'config': 'config 4: power-law digraph N=2M E=40M, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
-                      'train fwd+bwd+Adam + eval fwd' + (', ShardedChebNet' if multi else '')}
+            'config': 'config 4: power-law digraph N=%d E=%d, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
+                      'train fwd+bwd+Adam + eval fwd' % (n, e) + (', ShardedChebNet' if multi else '')}
 
 
 def edge_source(args, n, e, dev, chunk=50_000_000):
@@ -256,6 +259,16 @@ def edge_source(args, n, e, dev, chunk=50_000_000):
     return chunks
 
 
+def note(rank, msg):
+    """Progress on stderr (rank 0): a long run shows where it is; stdout stays reserved for the JSON line."""
+    if rank == 0:
+        sys.stderr.write('[bench %6.1fs] %s\n' % (time.time() - T_START, msg))
+        sys.stderr.flush()
+
+
+T_START = time.time()
+
+
 def timed_steps(step, steps, dev, multi):
     """Wall time of `steps` calls bracketed by barrier + synchronize, maximum over the ranks."""
     import torch.distributed as dist
@@ -271,7 +284,8 @@ def timed_steps(step, steps, dev, multi):
     elapsed = time.perf_counter() - t0
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        from magnet_amd.dist import all_reduce
+        all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     return elapsed
 
@@ -288,6 +302,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    # MH_DIST_BACKEND=gloo: rehearsal of the multi-rank code on fewer GPUs than ranks (ranks share devices, transfers are
+    # staged through host memory by magnet_amd.dist.start_transfers); its timings say nothing about xGMI
+    backend = os.environ.get('MH_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -298,7 +317,7 @@ def main():
             for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533')):
                 os.environ.setdefault(k, v)
         # a collective that cannot complete ends the run after 5 minutes instead of the 10-minute default
-        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=5))
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=5), **({'device_id': dev} if backend == 'nccl' else {}))
 
     from magnet_amd import laplacian as lapmod
     from magnet_amd.laplacian import build_magnetic_laplacian
@@ -330,16 +349,17 @@ def main():
         t0 = time.time()
         lap_blk, bounds = D.build_row_block(chunks, n, rank, world, q=args.q)
         torch.cuda.synchronize()
+        note(rank, 'row block built (%d of %d rows)' % (lap_blk.n_rows, n))
         t_build = time.time() - t0
         build_device_ms = None
         counts = torch.tensor([lap_blk.nnz], device=dev, dtype=torch.int64)
-        dist.all_reduce(counts)
+        D.all_reduce(counts)
         nnz_total = int(counts.item())
         part_probe = D.RowPartition(lap_blk.row_ptr, lap_blk.col_idx, lap_blk.val, n, bounds, rank, world,
                                     lambda rp, ci, v, nc: lapmod.MagneticLaplacian(rp, ci, v, nc))
         worst = torch.tensor([part_probe.n_halo, part_probe.sent_rows(), lap_blk.nnz, part_probe.n_local], device=dev,
                              dtype=torch.int64)
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        D.all_reduce(worst, op=dist.ReduceOp.MAX)
         halo_max, sent_max, nnz_max, rows_max = (int(v) for v in worst.tolist())
         rows_floats = D.row_partition_floats(halo_max, f, K)
         cols_floats = D.column_sharding_floats(n, f, K, world)
@@ -386,12 +406,14 @@ def main():
     def observer(ev0, ev1, info):
         launches.append((ev0, ev1, info))
 
+    note(rank, 'set-up done (nnz %d, strategy %s); warm-up' % (nnz_total, strategy))
     for _ in range(args.warmup):
         step()
     launches.clear()
     lapmod.SPMM_OBSERVER = observer
     elapsed = timed_steps(step, args.steps, dev, multi)
     lapmod.SPMM_OBSERVER = None
+    note(rank, '%d timed steps: %.1f ms per step' % (args.steps, elapsed / args.steps * 1e3))
 
     # dominant kernel: the fused complex SpMM, timed by HIP events on its own stream
     k_ms = sum(a.elapsed_time(b) for a, b, _ in launches)
@@ -428,6 +450,7 @@ def main():
             dist_info['note'] = 'single-rank rehearsal of the multi-GPU code path: no bytes cross a link'
 
     ceiling = stream_ceilings(dev) if rank == 0 else None
+    note(rank, 'headline complete; secondary measurements follow')
 
     out = None
     if rank == 0:
@@ -520,8 +543,9 @@ def main():
         step = launches = None
         layer = conv = xp = block = lap = lap_blk = None
         torch.cuda.empty_cache()
+        note(rank, 'epoch measurement (config 4)')
         try:
-            epoch = epoch_time(rank, world, dev, multi)
+            epoch = epoch_time(rank, world, dev, multi, args.epoch_nodes, args.epoch_edges)
         except Exception as ex:                         # the headline metric must still be reported
             epoch = {'error': repr(ex)[:300]}
         if out is not None:
@@ -531,6 +555,7 @@ def main():
     watchdog.cancel()                                   # the GPU work is over; the CPU baseline has its own bound
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         args.full_nnz = nnz_total
+        note(rank, 'CPU baseline on a sample (host cores)')
         try:
             out['cpu_baseline'] = cpu_baseline(args)
         except Exception as ex:

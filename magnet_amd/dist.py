@@ -82,6 +82,52 @@ def wait_all(works):
         w.wait()
 
 
+class _StagedTransfer:
+    """A point-to-point transfer of a device tensor carried by a host copy (gloo moves host memory only)."""
+
+    def __init__(self, work, host, target):
+        self.work, self.host, self.target = work, host, target
+
+    def wait(self):
+        self.work.wait()
+        if self.target is not None:
+            self.target.copy_(self.host)
+
+
+def all_reduce(t, op=None, group=None):
+    """dist.all_reduce in place; over gloo a device tensor is reduced through a host copy (see start_transfers)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def start_transfers(ops, group=None):
+    """ops: [('send' | 'recv', tensor, peer), ...] issued as ONE batch of point-to-point transfers (on the fully
+    connected xGMI mesh every pair of GPUs has its own link, so a batch to all peers runs concurrently).  Returns
+    handles with .wait().  Over RCCL (backend "nccl") the tensors travel device to device.  The gloo backend —
+    the CPU rehearsal of this logic, and the one-GPU rehearsal of the multi-rank code, where several ranks share a
+    device and RCCL cannot be used — moves host memory only: device tensors are staged through host copies there."""
+    if not ops:
+        return []
+    if not (dist.get_backend(group) == 'gloo' and any(t.is_cuda for _, t, _ in ops)):
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == 'send' else dist.irecv, t, peer, group)
+                                       for kind, t, peer in ops])
+    works = []
+    for kind, t, peer in ops:
+        if kind == 'send':
+            host = t.cpu()                                   # waits for the stream that produced t
+            works.append(_StagedTransfer(dist.isend(host, peer, group), host, None))
+        else:
+            host = torch.empty(t.shape, dtype=t.dtype)
+            works.append(_StagedTransfer(dist.irecv(host, peer, group), host, t))
+    return works
+
+
 class TorchRowMover:
     """Index-based stand-in for the halo staging kernels (CPU rehearsal over gloo)."""
 
@@ -134,7 +180,8 @@ def exchange_index_lists(send, rank, world, group=None):
     recv = [None] * world
     if world == 1:
         return recv
-    counts = torch.tensor([0 if p == rank else int(send[p].numel()) for p in range(world)], dtype=torch.int64, device=dev)
+    cdev = 'cpu' if dist.get_backend(group) == 'gloo' else dev       # gloo gathers host tensors
+    counts = torch.tensor([0 if p == rank else int(send[p].numel()) for p in range(world)], dtype=torch.int64, device=cdev)
     table = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(table, counts, group=group)
     ops = []
@@ -142,11 +189,10 @@ def exchange_index_lists(send, rank, world, group=None):
         to, frm = (rank + step) % world, (rank - step) % world
         recv[frm] = torch.empty(int(table[frm][rank]), dtype=torch.int32, device=dev)
         if send[to].numel():
-            ops.append(dist.P2POp(dist.isend, send[to].contiguous(), to, group))
+            ops.append(('send', send[to].contiguous(), to))
         if recv[frm].numel():
-            ops.append(dist.P2POp(dist.irecv, recv[frm], frm, group))
-    if ops:
-        wait_all(dist.batch_isend_irecv(ops))
+            ops.append(('recv', recv[frm], frm))
+    wait_all(start_transfers(ops, group))
     return recv
 
 
@@ -256,12 +302,11 @@ class RowPartition:
             g = self.give[to]
             if g.numel():
                 mine = buf[:nl] if g.numel() == nl else self.mover.gather(buf, g)   # ascending + complete = the block itself
-                ops.append(dist.P2POp(dist.isend, mine, to, self.group))
+                ops.append(('send', mine, to))
                 staged.append(mine)                                  # keep the send buffer alive
             if pp[frm + 1] > pp[frm]:
-                ops.append(dist.P2POp(dist.irecv, buf[nl + pp[frm]:nl + pp[frm + 1]], frm, self.group))
-        works = dist.batch_isend_irecv(ops) if ops else []
-        return (works, staged)
+                ops.append(('recv', buf[nl + pp[frm]:nl + pp[frm + 1]], frm))
+        return (start_transfers(ops, self.group), staged)
 
     def finish_exchange(self, handle):
         if handle:
@@ -349,7 +394,7 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
     dinv = torch.zeros(n, dtype=torch.float32, device=dev)
     dinv[r0:r1] = build.dinv_block
     if world > 1:
-        dist.all_reduce(dinv, group=group)
+        all_reduce(dinv, group=group)
     return build.finish(dinv, q), bounds
 
 
@@ -414,10 +459,10 @@ def all_to_all_blocks(send, recv, rank, world, group=None, enabled=True):
     for step in range(1, world):
         to, frm = (rank + step) % world, (rank - step) % world
         if send[to].numel():
-            ops.append(dist.P2POp(dist.isend, send[to], to, group))
+            ops.append(('send', send[to], to))
         if recv[frm].numel():
-            ops.append(dist.P2POp(dist.irecv, recv[frm], frm, group))
-    return dist.batch_isend_irecv(ops) if ops else []
+            ops.append(('recv', recv[frm], frm))
+    return start_transfers(ops, group)
 
 
 class ColumnSharded:
@@ -510,11 +555,11 @@ class ColumnSharded:
             recv[frm] = torch.empty((rows_me, 2, self.cb[frm + 1] - self.cb[frm]), dtype=z.dtype, device=z.device)
             ops = []
             if part.numel():
-                ops.append(dist.P2POp(dist.isend, part, to, self.group))
+                ops.append(('send', part, to))
             if recv[frm].numel():
-                ops.append(dist.P2POp(dist.irecv, recv[frm], frm, self.group))
-            if ops and self.comm_enabled:
-                works += dist.batch_isend_irecv(ops)
+                ops.append(('recv', recv[frm], frm))
+            if self.comm_enabled:
+                works += start_transfers(ops, self.group)
         recv[self.rank] = block(self.rank)
         return works, recv, z
 
@@ -692,7 +737,7 @@ class ShardedChebNet:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             if self.world > 1:
-                dist.all_reduce(p.grad, group=self.group)
+                all_reduce(p.grad, group=self.group)
 
     def epoch(self, opt, x_rows, label_rows, train_rows, val_rows, n_train, n_val):
         """One epoch of the reference loop (src/sparse_Magnet.py:143-176) on this rank's rows:
@@ -712,5 +757,5 @@ class ShardedChebNet:
             vloss = F.nll_loss(preds[:, :, val_rows], label_rows[:, val_rows], reduction='sum') / n_val
         stats = torch.stack([loss.detach(), vloss])
         if self.world > 1:
-            dist.all_reduce(stats, group=self.group)
+            all_reduce(stats, group=self.group)
         return stats[0], stats[1]

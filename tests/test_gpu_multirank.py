@@ -1,0 +1,133 @@
+"""The multi-rank code with REAL processes and the REAL HIP kernels on one GPU: world_size 2 and 3 ranks share
+cuda:0 and talk over gloo (RCCL needs one GPU per rank; magnet_amd.dist stages device tensors through host memory
+on that backend).  What runs is what bench.py --gpus N runs on an 8-GPU node, transport aside: every rank builds
+only its row block (mh_lap_block_*), plans its halo (mh_halo_plan_*), exchanges need lists, propagates with the
+packed halo exchange — and the column-sharded conv — against the single-GPU result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+N, E, F, TERMS, SEED = 30_000, 600_000, 32, 4, 12
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _chunks(dev, weighted):
+    from magnet_amd.laplacian import powerlaw_edges
+
+    def gen():
+        for first in range(0, E, 250_000):                      # several chunks, as the bench streams them
+            src, dst = powerlaw_edges(N, min(250_000, E - first), SEED, first_edge=first, device=dev)
+            if weighted:
+                w = ((src.long() * 7 + dst.long() * 3 + first) % 5 + 1).float() * 0.5
+                yield src, dst, w
+            else:
+                yield src, dst
+    return gen
+
+
+def _worker(rank, world, port, out_dir, weighted):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from magnet_amd import dist as D
+        from magnet_amd.laplacian import MagneticLaplacian
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        blk, bounds = D.build_row_block(_chunks(dev, weighted), N, rank, world, q=0.2)
+        make = lambda rp, ci, v, nc: MagneticLaplacian(rp, ci, v, nc)
+        part = D.RowPartition(blk.row_ptr, blk.col_idx, blk.val, N, bounds, rank, world, make)
+        x = torch.randn(N, 2, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        xb = part.new_buffer(F, dev); xb.fill_(float('nan'))
+        part.block(xb).copy_(x[part.r0:part.r1])
+        zs = part.cheb_terms(xb, TERMS)
+        # column-sharded conv on the same graph (every rank holds the whole CSR in that layout)
+        full, _ = D.build_row_block(_chunks(dev, weighted), N, 0, 1, q=0.2)
+        g = torch.Generator().manual_seed(5)
+        W = torch.randn(TERMS, F, 8, generator=g).to(dev); b = torch.randn(1, 8, generator=g).to(dev)
+        sh = D.ColumnSharded(full, N, F, rank, world)
+        out = sh.conv(x[:, :, sh.c0:sh.c1].contiguous(), W, b)
+        torch.cuda.synchronize()
+        torch.save({'bounds': bounds, 'row_ptr': blk.row_ptr.cpu(), 'col_idx': blk.col_idx.cpu(), 'val': blk.val.cpu(),
+                    'blocks': [part.block(z).cpu() for z in zs], 'n_halo': part.n_halo, 'sent': part.sent_rows(),
+                    'cols_out': out.cpu(), 'rb': sh.rb}, os.path.join(out_dir, 'r%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,weighted', [(2, False), (3, True)])
+def test_ranks_sharing_one_gpu_match_the_single_gpu_result(world, weighted, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), weighted), nprocs=world, join=True)
+    from magnet_amd.laplacian import build_magnetic_laplacian
+    dev = torch.device('cuda', 0)
+    parts = [torch.cat(t) for t in zip(*_chunks(dev, weighted)())]
+    L = build_magnetic_laplacian(parts[0], parts[1], N, q=0.2, edge_weight=parts[2] if weighted else None)
+    outs = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    bounds = outs[0]['bounds']
+    assert bounds[0] == 0 and bounds[-1] == N and all(o['bounds'] == bounds for o in outs)
+    # the per-rank blocks, stacked, are the single-GPU CSR bit for bit
+    rp, ci, v = L.row_ptr.cpu(), L.col_idx.cpu(), L.val.cpu()
+    for r, o in enumerate(outs):
+        a, z = int(rp[bounds[r]]), int(rp[bounds[r + 1]])
+        assert torch.equal(o['row_ptr'], rp[bounds[r]:bounds[r + 1] + 1] - rp[bounds[r]])
+        assert torch.equal(o['col_idx'], ci[a:z]) and torch.equal(o['val'], v[a:z])
+    assert sum(o['sent'] for o in outs) == sum(o['n_halo'] for o in outs) > 0
+    # propagation
+    x = torch.randn(N, 2, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    ref = [x, L.spmm(x)]
+    for k in range(2, TERMS):
+        ref.append(L.spmm(ref[k - 1], alpha=2.0, z1=ref[k - 2], beta1=-1.0))
+    for k in range(TERMS):
+        got = torch.cat([o['blocks'][k] for o in outs]).to(dev)
+        assert float((got - ref[k]).abs().max()) <= 1e-5 * float(ref[k].abs().max()), 'order %d' % k
+    # column-sharded conv
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(TERMS, F, 8, generator=g).to(dev); b = torch.randn(1, 8, generator=g).to(dev)
+    want = sum(torch.matmul(ref[k], W[k]) for k in range(TERMS)) + b.view(1, 1, -1)
+    got = torch.cat([o['cols_out'] for o in outs]).to(dev)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('strategy', ['rows', 'cols'])
+def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
+    """bench.py launched as the driver launches it for --gpus 2 (torch.distributed.run, one process per rank), both
+    ranks on this GPU over gloo: the whole multi-rank control flow (per-rank build, strategy record, timed steps,
+    compute-only steps, secondary measurements) ends with one JSON line on rank 0."""
+    env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--nodes', '200000',
+           '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy, '--no-cpu-baseline']
+    # the column-sharded run also takes the secondary measurements: the same conv row-partitioned, and a training epoch
+    # of the sharded ChebNet (on a small graph here)
+    cmd += ['--no-epoch'] if strategy == 'rows' else ['--epoch-nodes', '50000', '--epoch-edges', '1000000']
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == strategy + '2' and d['value'] > 0
+    m = d['multi_gpu']
+    assert m['ranks_initialised'] == 2 and m['strategy'] == strategy and m['backend'] == 'gloo'
+    assert m['row_layout']['largest_halo_rows'] > 0 and m['row_layout']['bytes_sent_per_rank_per_order'] > 0
+    assert m['compute_only_ms_per_step'] > 0 and np.isfinite(m['exposed_comm_ms_per_step'])
+    assert 0 < m['row_layout']['largest_block_nnz'] < d['config']['nnz']
+    if strategy == 'cols':
+        assert d['row_partition']['ms_per_step'] > 0 and np.isfinite(d['row_partition']['exposed_comm_ms_per_step'])
+        assert d['epoch']['ms'] > 0 and d['epoch']['n_gpus'] == 2 and d['epoch']['ms_with_cached_input_propagation'] > 0
