@@ -490,6 +490,8 @@ def main():
                 'note': 'streamed bytes of all builder kernels (bench.py: builder_bytes) / HIP-event time of the whole build; '
                         'the random d^-1/2 reads of the emission are not in the model'},
             'multi_gpu': dist_info,
+            'device': {'name': torch.cuda.get_device_properties(dev).name, 'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', '')),
+                       'hbm_gb': torch.cuda.get_device_properties(dev).total_memory / 1e9},
             'epoch': None,
         }
 
