@@ -416,8 +416,14 @@ def link_split_cases(ref_h, ref_c, ChebNet_Edge):
     n_citeseer = int(max(c['adj_indices'].max() + 1, len(c['adj_indptr']) - 1))
     out = {}
     names = []
-    for name, rel, task, size in [('citeseer_task1', 'citeseer/task1dim2prob15_5.pk', 1, n_citeseer),
-                                  ('cora_ml_task2', 'cora_ml/task2dim2prob15_5.pk', 2, None)]:
+    # K = 2 on the citation graphs (BASELINE configuration 3); K = 1 with q from the sweep's grid on the WebKB splits, the
+    # setting of execution/link_prediction.sh:23,44.  (name, cache, task, node count or None, K, q, floor for the node count)
+    cases = [('citeseer_task1', 'citeseer/task1dim2prob15_5.pk', 1, n_citeseer, 2, 0.1, 0),
+             ('cora_ml_task2', 'cora_ml/task2dim2prob15_5.pk', 2, None, 2, 0.1, 2995),
+             ('cornell_task1', 'WebKB/Cornell/Cornelltask1dim2prob15_5.pk', 1, None, 1, 0.25, 183),
+             ('cornell_task2', 'WebKB/Cornell/Cornelltask2dim2prob15_5.pk', 2, None, 1, 0.1, 183),
+             ('texas_task2', 'WebKB/Texas/Texastask2dim2prob15_5.pk', 2, None, 1, 0.2, 183)]
+    for name, rel, task, size, K, q, floor in cases:
         with open(os.path.join(REF, 'dataset/data/tmp', rel), 'rb') as f:
             splits = to_numpy(load_inert(f.read()))
         d = splits[0]
@@ -425,15 +431,15 @@ def link_split_cases(ref_h, ref_c, ChebNet_Edge):
         parts = {k: (np.asarray(d[k]['pairs']).astype(np.int64), np.asarray(d[k]['label']).astype(np.int64))
                  for k in ('train', 'validate', 'test')}
         if size is None:
-            # cora_ml.npz is not shipped: the driver's size = max(edge_index) + 1 of the full graph is bounded
-            # below by every node id the split mentions; Cora-ML has 2 995 nodes
-            size = max(2995, int(edges.max()) + 1, max(int(p.max()) + 1 for p, _ in parts.values()))
+            # the full graph is not shipped (cora_ml.npz) or not read here: the driver's size = max(edge_index) + 1 is
+            # bounded below by every node id the split mentions; Cora-ML has 2 995 nodes, Cornell and Texas 183
+            size = max(floor, int(edges.max()) + 1, max(int(p.max()) + 1 for p, _ in parts.values() if len(p)))
         names.append(name)
-        L = ref_c(ref_h(edges[0], edges[1], size, 0.1, True, True, 2.0, False, None), 2)
+        L = ref_c(ref_h(edges[0], edges[1], size, q, True, True, 2.0, False, None), K)
         Lr, Li = to_coo_lists(L)
         X = in_out_degree(edges, size)
         torch.manual_seed(500 + task)
-        net = ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0)
+        net = ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=K, label_dim=2, activation=True, layer=2, dropout=0.0)
         for m in net.Chebs:
             if hasattr(m, 'bias'):
                 with torch.no_grad():
@@ -446,15 +452,16 @@ def link_split_cases(ref_h, ref_c, ChebNet_Edge):
         with torch.no_grad():
             ov = net(X.clone(), X.clone(), vp)
             vloss = torch.nn.functional.nll_loss(ov, vl)
-        L64 = ref_c(L[1].astype(np.complex128), 2)
+        L64 = ref_c(L[1].astype(np.complex128), K)
         Lr64, Li64 = to_coo_lists(L64, np.float64)
-        net64 = ChebNet_Edge(X.size(-1), Lr64, Li64, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0).double()
+        net64 = ChebNet_Edge(X.size(-1), Lr64, Li64, num_filter=16, K=K, label_dim=2, activation=True, layer=2, dropout=0.0).double()
         net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
         o64 = net64(X.double(), X.double(), tp)
         loss64 = torch.nn.functional.nll_loss(o64, tl)
         loss64.backward()
         pre = name + '/'
         out[pre + 'graph'] = edges.numpy().astype(np.int32); out[pre + 'size'] = np.array(size)
+        out[pre + 'params'] = np.array([K, q, task], np.float64)
         for k, (p, l) in parts.items():
             out[pre + k + '/pairs'] = p.astype(np.int32); out[pre + k + '/label'] = l.astype(np.int8)
         out[pre + 'X'] = X.numpy()

@@ -477,29 +477,30 @@ LINKS = load_golden('link_split_cases.npz')
 @pytest.mark.parametrize('name', [str(s) for s in LINKS['names']])
 def test_reference_link_splits_step(name, mode):
     """BASELINE configuration 3 on the reference's own artefacts: split 0 of the link-split caches it ships
-    (citeseer/task1dim2prob15_5.pk: existence; cora_ml/task2dim2prob15_5.pk: direction), K = 2, q = 0.1,
-    16 filters — the observed graph's Laplacian (structure exact), the driver's degree features, one training
+    (citeseer/task1dim2prob15_5.pk: existence; cora_ml/task2dim2prob15_5.pk: direction; K = 2, q = 0.1) and the WebKB
+    Cornell / Texas splits with the sweep's K = 1 (execution/link_prediction.sh:23,44), 16 filters — the observed graph's Laplacian (structure exact), the driver's degree features, one training
     step of ChebNet_Edge on the split's training pairs (outputs, loss, every parameter gradient) and the
     evaluation forward on its validation pairs, against the reference's float32 run and its float64 companion."""
     _, lap, H, M, O = _mods()
     from magnet_amd.utils.edge_data import in_out_degree
     g, pre = LINKS, name + '/'
     size = int(g[pre + 'size'])
+    K, q = int(g[pre + 'params'][0]), float(g[pre + 'params'][1])
     edges = torch.from_numpy(g[pre + 'graph'].astype(np.int64)).to(DEV)
-    L = H.hermitian_decomp_sparse_device(edges[0], edges[1], size, 0.1)
+    L = H.hermitian_decomp_sparse_device(edges[0], edges[1], size, q)
     Ls = L.to_scipy()
     assert np.array_equal(Ls.indptr, g[pre + 'indptr']) and np.array_equal(Ls.indices, g[pre + 'indices'])
     assert_close(Ls.data.real, g[pre + 'data'].real); assert_close(Ls.data.imag, g[pre + 'data'].imag)
     X = in_out_degree(edges, size).to(DEV)
     assert np.array_equal(X.cpu().numpy(), g[pre + 'X'])
     if mode == 'basis':
-        Lr, Li = H.cheb_poly_sparse(L, 2), None
+        Lr, Li = H.cheb_poly_sparse(L, K), None
     else:
         Lo = sp.csr_matrix((g[pre + 'data'], g[pre + 'indices'], g[pre + 'indptr']), shape=(size, size))
-        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, 2))
+        Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(Lo, K))
         Lr = [t.to(DEV) for t in Lr]; Li = [t.to(DEV) for t in Li]
     state = {k[len(pre) + 6:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(pre + 'state/')}
-    net = M.ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=2, label_dim=2, activation=True, layer=2, dropout=0.0).to(DEV)
+    net = M.ChebNet_Edge(X.size(-1), Lr, Li, num_filter=16, K=K, label_dim=2, activation=True, layer=2, dropout=0.0).to(DEV)
     net.load_state_dict(state)
     tp = torch.from_numpy(g[pre + 'train/pairs'].astype(np.int64)).to(DEV)
     tl = torch.from_numpy(g[pre + 'train/label'].astype(np.int64)).to(DEV)
@@ -514,7 +515,8 @@ def test_reference_link_splits_step(name, mode):
     for k, p in net.named_parameters():
         assert_close(c(p.grad), g[pre + 'grad/' + k], what='grad ' + k)
         t = g[pre + 'truth/grad/' + k]
-        assert np.abs(c(p.grad) - t).max() <= 1e-5 * np.abs(t).max() + 1e-9, 'grad %s vs float64' % k
+        # (+1e-7 absolute, the floor of assert_close: a two-class bias gradient is a cancelling sum of O(1) terms)
+        assert np.abs(c(p.grad) - t).max() <= 1e-5 * np.abs(t).max() + 1e-7, 'grad %s vs float64' % k
     net.eval()
     with torch.no_grad():
         ov = net(X.clone(), X.clone(), torch.from_numpy(g[pre + 'validate/pairs'].astype(np.int64)).to(DEV))

@@ -167,21 +167,22 @@ def test_citeseer_link_case():
     assert_close(out, g['out'], what='out')
 
 
-@pytest.mark.parametrize('name', ['citeseer_task1', 'cora_ml_task2'])
+@pytest.mark.parametrize('name', ['citeseer_task1', 'cora_ml_task2', 'cornell_task1', 'cornell_task2', 'texas_task2'])
 def test_reference_link_splits_step(name):
     """Configuration 3 on split 0 of the link-split caches the reference ships (citeseer existence, cora_ml
-    direction): the oracle against the reference's Laplacian, degree features, training-pair outputs, loss,
+    direction, K = 2; the WebKB Cornell / Texas splits with the sweep's K = 1): the oracle against the reference's Laplacian, degree features, training-pair outputs, loss,
     validation outputs and every parameter gradient."""
     g = load_golden('link_split_cases.npz')
     pre = name + '/'
     size = int(g[pre + 'size'])
+    K, q = int(g[pre + 'params'][0]), float(g[pre + 'params'][1])
     edges = torch.from_numpy(g[pre + 'graph'].astype(np.int64))
-    L = O.hermitian_decomp_sparse(edges[0].numpy(), edges[1].numpy(), size, 0.1)
+    L = O.hermitian_decomp_sparse(edges[0].numpy(), edges[1].numpy(), size, q)
     assert np.array_equal(L.indptr, g[pre + 'indptr']) and np.array_equal(L.indices, g[pre + 'indices'])
     assert_close(L.data, g[pre + 'data'], rel=1e-6)
     X = O.in_out_degree(edges, size)
     assert np.array_equal(X.numpy(), g[pre + 'X'])
-    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(L, 2))
+    Lr, Li = O.laplacian_lists(O.cheb_poly_sparse(L, K))
     state = {k[len(pre) + 6:]: torch.from_numpy(g[k].copy()).requires_grad_(True) for k in g.files if k.startswith(pre + 'state/')}
     tp = torch.from_numpy(g[pre + 'train/pairs'].astype(np.int64)); tl = torch.from_numpy(g[pre + 'train/label'].astype(np.int64))
     out = O.chebnet_edge_forward(state, Lr, Li, X, X, tp, 2, True)
@@ -195,7 +196,9 @@ def test_reference_link_splits_step(name):
     with torch.no_grad():
         ov = O.chebnet_edge_forward(state, Lr, Li, X, X, torch.from_numpy(g[pre + 'validate/pairs'].astype(np.int64)), 2, True)
     assert_close(ov, g[pre + 'val_out'], what='validation out')
-    assert len(tp) == {'citeseer_task1': 7345, 'cora_ml_task2': 6321}[name] and edges.size(1) == {'citeseer_task1': 3763, 'cora_ml_task2': 6589}[name]
+    counts = {'citeseer_task1': (7345, 3763), 'cora_ml_task2': (6321, 6589), 'cornell_task1': (210, 227),
+              'cornell_task2': (209, 227), 'texas_task2': (204, 239)}
+    assert (len(tp), edges.size(1)) == counts[name]
 
 
 def test_structure_rules():
