@@ -251,7 +251,7 @@ def telegram_cache():
     read with the inert opcode walker (nothing in the files is executed) and re-stored as
     plain arrays: T_1 of every cache and T_2 of the K=2 ones."""
     sys.path.insert(0, os.path.join(HERE, '..', '..'))
-    from tools.inert_pickle import read_sparse_list
+    from magnet_amd.utils.inert_pickle import read_sparse_list
     import glob
     out = {}
     names = []
