@@ -525,6 +525,35 @@ def test_reference_link_splits_step(name, mode):
     assert abs(vloss.item() - float(g[pre + 'val_loss'])) <= 1e-5 * float(g[pre + 'val_loss'])
 
 
+def test_c_abi_from_a_plain_cpp_caller():
+    """tests/abi/abi_client.cpp — plain C++ + the HIP runtime, no torch, no Python — builds a Laplacian and applies one
+    propagation order through the C ABI (mh_lap_build_*, mh_cspmm, mh_cspmm_planned_noalloc); its printed CSR and result
+    against the CPU oracle."""
+    import subprocess
+    from conftest import ROOT
+    _, lap, H, M, O = _mods()
+    exe = os.path.join(ROOT, 'tests', 'abi', 'abi_client')
+    assert os.path.isfile(exe), 'tests/abi/abi_client is not built (make -C magnet_amd/csrc)'
+    n, e, f, q = 300, 5000, 8, 0.25
+    res = subprocess.run([exe, str(n), str(e), str(f), str(q)], capture_output=True, text=True, timeout=100)
+    assert res.returncode == 0, res.stderr[-1000:]
+    lines = {l.split(' ', 1)[0]: l.split(' ')[1:] for l in res.stdout.strip().splitlines()}
+    i = np.arange(e, dtype=np.int64)
+    src, dst = (7 * i + 3) % n, (i * i + 5 * i + 1) % n
+    Lo = O.hermitian_decomp_sparse(src, dst, n, q)
+    assert int(lines['version'][0]) >= 200 and int(lines['version'][2]) == Lo.nnz
+    assert np.array_equal(np.array(lines['row_ptr'], np.int64), Lo.indptr)
+    assert np.array_equal(np.array(lines['col'], np.int64), Lo.indices)
+    val = np.array(lines['val'], np.float64).reshape(-1, 2)
+    assert_close(val[:, 0], Lo.data.real); assert_close(val[:, 1], Lo.data.imag)
+    ii, pp, cc = np.meshgrid(np.arange(n), np.arange(2), np.arange(f), indexing='ij')
+    x = np.sin(0.37 * ii + 1.1 * cc + 0.5 * pp).astype(np.float32).astype(np.float64)
+    xc = x[:, 0] + 1j * x[:, 1]
+    want = 2.0 * (Lo.astype(np.complex128) @ xc) - xc
+    y = np.array(lines['y'], np.float64).reshape(n, 2, f)
+    assert_close(y[:, 0], want.real); assert_close(y[:, 1], want.imag)
+
+
 def test_magnetconv_edge_index_signature():
     _, lap, H, M, O = _mods()
     row, col, n, _ = _telegram(0.25, False)
