@@ -888,6 +888,18 @@ def test_link_driver_runs_all_tasks(tmp_path):
                    '--num_filter', '8', '--splits', '1', '--log_root', root2, '--data_path', root2])
     assert res.shape[0] == 1 and np.isfinite(res).all()
     assert glob.glob(root2 + 'splits/**/*.pk', recursive=True) == []
+    # --hip_graph replays the same epochs: the logged losses follow the eager run
+    import re
+    logs = {}
+    for tag, extra in (('eager', []), ('graph', ['--hip_graph'])):
+        r3 = '%s/%s/' % (tmp_path, tag)
+        torch.manual_seed(1)                      # the driver, like the reference's, does not seed the model itself
+        drv.run(['--dataset', 'syn/cyclic', '--task', '2', '--num_class_link', '3', '--q', '0.1', '--K', '2', '-a', '--num_filter', '8',
+                 '--dropout', '0', '--true_degrees', '--epochs', '15', '--splits', '1', '--log_root', r3, '--data_path', r3])
+        text = open(glob.glob(r3 + '**/log0.csv', recursive=True)[0]).read()
+        logs[tag] = np.array([[float(a), float(b)] for a, b in re.findall(r'Train loss: ([0-9.]+),.*? Test loss: ([0-9.]+),', text)])
+    assert logs['eager'].shape == (15, 2) and logs['graph'].shape == (15, 2)
+    assert np.abs(logs['eager'] - logs['graph']).max() <= 2e-4, np.abs(logs['eager'] - logs['graph']).max()
     # a real run on the CiteSeer graph of the golden fixture: direction task, true degree features
     _, lap, H, M, O = _mods()
     from magnet_amd.utils.preprocess import to_edge_dataset_sparse
