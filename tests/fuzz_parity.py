@@ -271,18 +271,97 @@ def net_case(rng, row, col, n, q, w, L, S):
     return 'net ok K=%d layer=%d F=%d cin=%d act=%d edge=%d' % (K, layer, F, cin, act, edge)
 
 
+def dist_case(rng):
+    """The multi-GPU building blocks on a random graph, all ranks emulated in this process: per-rank row blocks
+    (mh_lap_block_*) stacked against the whole-graph build (bit for bit), the halo plan kernels against their tensor
+    restatement, and the recursion on compact [own | halo] buffers with a packed exchange against the single-GPU
+    recursion."""
+    from magnet_amd import dist as D
+    from magnet_amd import laplacian as lapmod
+    dev = torch.device('cuda', 0)
+    n = int(rng.choice([1, 2, 5, 40, 300, 3000, 30000]))
+    e = int(rng.integers(0, 25 * n + 1))
+    world = int(rng.integers(1, 6))
+    row = torch.from_numpy(rng.integers(0, n, e)).to(dev); col = torch.from_numpy(rng.integers(0, n, e)).to(dev)
+    if e > 4 and rng.integers(0, 2):
+        k = e // 3
+        row[:k], col[:k] = col[k:2 * k].clone(), row[k:2 * k].clone()            # reciprocal pairs
+    if rng.integers(0, 3) == 0 and e > 200:
+        row[-150:] = row[0]; col[-150:] = col[0]                                   # one directed pair 150 times: a long run
+    kind = int(rng.integers(0, 3))
+    w = None if kind == 0 else (torch.from_numpy(rng.integers(1, 9, e).astype(np.float32)).to(dev) if kind == 1
+                                else torch.from_numpy(rng.random(e).astype(np.float32)).to(dev))
+    if rng.integers(0, 2):
+        row, col = row.int(), col.int()
+    q = float(rng.choice([0.0, 0.1, 0.25, rng.random() * 0.5])); lam = float(rng.choice([2.0, 2.0, 3.0]))
+    L = lapmod.build_magnetic_laplacian(row, col, n, q=q, edge_weight=w, max_eigen=lam)
+    deg = torch.bincount(row.long(), minlength=n) + torch.bincount(col.long(), minlength=n)
+    bounds = D.bounds_from_degrees(deg, world)
+    builds = []
+    for r in range(world):
+        r0, r1 = bounds[r], bounds[r + 1]
+        fm, bm = (row >= r0) & (row < r1), (col >= r0) & (col < r1)
+        fwd = (row[fm], col[fm]) + ((w[fm],) if w is not None else ())
+        bwd = (row[bm], col[bm]) + ((w[bm],) if w is not None else ())
+        builds.append(lapmod.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam))
+    dinv = torch.cat([b.dinv_block for b in builds])
+    assert torch.equal(dinv, L.dinv), 'dinv'
+    blocks = [b.finish(dinv, q) for b in builds]
+    make = lambda rp, ci, v, nc: lapmod.MagneticLaplacian(rp, ci, v, nc)
+    parts = []
+    for r, blk in enumerate(blocks):
+        rp, ci, v = D.slice_rows(L.row_ptr, L.col_idx, L.val, bounds[r], bounds[r + 1])
+        assert torch.equal(blk.row_ptr, rp) and torch.equal(blk.col_idx, ci) and torch.equal(blk.val, v), 'block %d of %d' % (r, world)
+        bt = torch.tensor(bounds, dtype=torch.int32, device=dev)
+        got, want = lapmod.halo_plan(ci, n, bounds[r], bounds[r + 1], bt), D.halo_plan_torch(ci, n, bounds[r], bounds[r + 1], bt)
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), 'halo plan of rank %d' % r
+        parts.append(D.RowPartition(blk.row_ptr, blk.col_idx, blk.val, n, bounds, r, world, make,
+                                    exchange_lists=lambda need, rank, world, group: [None] * world))
+    for r, p in enumerate(parts):
+        p.give = [None if o == r else parts[o].need[r] for o in range(world)]
+
+    def exchange(bufs):
+        for r, p in enumerate(parts):
+            for o, other in enumerate(parts):
+                if o != r and p.peer_ptr[o + 1] > p.peer_ptr[o]:
+                    bufs[r][p.n_local + p.peer_ptr[o]:p.n_local + p.peer_ptr[o + 1]] = D.HipRowMover.gather(bufs[o], other.give[r])
+    f = int(rng.choice([1, 3, 4, 16, 64])); terms = int(rng.integers(1, 5))
+    x = torch.randn(n, 2, f, device=dev, generator=torch.Generator(device=dev).manual_seed(int(rng.integers(0, 2 ** 31))))
+    ref = [x] + ([L.spmm(x)] if terms > 1 else [])
+    for k in range(2, terms):
+        ref.append(L.spmm(ref[k - 1], alpha=2.0, z1=ref[k - 2], beta1=-1.0))
+    zs = []
+    for p in parts:
+        b = p.new_buffer(f, dev); b.fill_(float('nan')); p.block(b).copy_(x[p.r0:p.r1]); zs.append([b])
+    exchange([z[0] for z in zs])
+    for k in range(1, terms):
+        new = [torch.full((p.n_buf, 2, f), float('nan'), device=dev) for p in parts]
+        for r, p in enumerate(parts):
+            p.propagate(zs[r][k - 1], new[r], 1.0 if k == 1 else 2.0, None if k == 1 else zs[r][k - 2], 0.0 if k == 1 else -1.0)
+        exchange(new)
+        for r in range(world):
+            zs[r].append(new[r])
+    scale = max(float(ref[-1].abs().max()), 1e-30)
+    for r, p in enumerate(parts):
+        if p.n_local:
+            err = float((p.block(zs[r][-1]) - ref[-1][p.r0:p.r1]).abs().max())
+            assert err <= 1e-5 * scale, 'recursion on rank %d: %.3e vs %.3e' % (r, err, scale)
+    return 'dist ok n=%d e=%d world=%d w=%d F=%d terms=%d nnz=%d halo=%s' % (n, e, world, kind, f, terms, L.nnz, [p.n_halo for p in parts])
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=100)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--first', type=int, default=0)
-    ap.add_argument('--kind', choices=['graph', 'spmm', 'aux'], default='graph')
+    ap.add_argument('--kind', choices=['graph', 'spmm', 'aux', 'dist'], default='graph')
     a = ap.parse_args()
     bad = 0
     for i in range(a.first, a.first + a.cases):
         rng = np.random.default_rng([a.seed, i])           # every case reproducible on its own (--first i --cases 1)
         try:
-            msg = spmm_case(rng) if a.kind == 'spmm' else aux_case(rng) if a.kind == 'aux' else one_case(rng, i)
+            msg = (spmm_case(rng) if a.kind == 'spmm' else aux_case(rng) if a.kind == 'aux' else dist_case(rng) if a.kind == 'dist'
+                   else one_case(rng, i))
         except Exception as ex:                            # keep going: report every failing case
             import traceback
             bad += 1
