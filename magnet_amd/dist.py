@@ -312,11 +312,13 @@ class RowPartition:
         if handle:
             wait_all(handle[0])
 
-    def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=None):
-        """z_out[own] = alpha * (L z_prev)[own] + beta * z_prev2[own].  `pending` is the handle of the
-        exchange that completes z_prev's halo; only the halo-column part waits for it."""
+    def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=None, add=None, add_beta=1.0):
+        """z_out[own] = alpha * (L z_prev)[own] + beta * z_prev2[own] (+ add_beta * add, a matrix of the rank's own
+        rows).  `pending` is the handle of the exchange that completes z_prev's halo; only the halo-column part
+        waits for it."""
         blk = self.block(z_out)
-        self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta)
+        self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta,
+                        z2=add, beta2=add_beta if add is not None else 0.0)
         self.finish_exchange(pending)
         if self.n_halo:
             self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
@@ -336,6 +338,45 @@ class RowPartition:
             zs.append(z)
             pending = self.exchange(z) if k < n_terms - 1 else None
         return zs
+
+
+    def clenshaw(self, ys):
+        """Own rows of sum_k T_k(L) Y_k for Y given by its own rows, ys[k] = [n_local, 2, F] (any strides):
+        b_K = Y_K, b_k = Y_k + 2 L b_{k+1} - b_{k+2}, result = Y_0 + L b_1 - b_2, every product with its halo
+        exchange.  This is also the backward of cheb_terms (T_k of a Hermitian L is Hermitian), so the gradient uses
+        the same blocks, the same plan and the same exchange."""
+        n_terms = len(ys)
+        f, dev = ys[0].size(2), ys[0].device
+        if n_terms == 1:
+            return ys[0].clone()
+        b1 = self.new_buffer(f, dev)
+        self.block(b1).copy_(ys[n_terms - 1])
+        b2 = None
+        for k in range(n_terms - 2, -1, -1):
+            pending = self.exchange(b1)
+            nb = self.new_buffer(f, dev)
+            self.propagate(b1, nb, 2.0 if k > 0 else 1.0, b2, -1.0 if b2 is not None else 0.0, pending=pending, add=ys[k])
+            b2, b1 = b1, nb
+        return self.block(b1)
+
+
+class _RowTermsFn(torch.autograd.Function):
+    """Own rows x [n_local, 2, F] of a row-partitioned matrix -> the orders T_k(L) x side by side, own rows only,
+    [n_local, 2, K+1, F].  Forward: K propagation orders with K halo exchanges.  Backward: the Clenshaw sum of the
+    incoming gradients over the same partition (K more orders, K more exchanges)."""
+
+    @staticmethod
+    def forward(ctx, x_own, part, n_terms):
+        f, dev = x_own.size(2), x_own.device
+        x_buf = part.new_buffer(f, dev)
+        part.block(x_buf).copy_(x_own)
+        zs = part.cheb_terms(x_buf, n_terms)
+        ctx.part = part
+        return torch.stack([part.block(z) for z in zs], dim=2)
+
+    @staticmethod
+    def backward(ctx, dz):
+        return ctx.part.clenshaw([dz[:, :, k, :] for k in range(dz.size(2))]), None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -759,3 +800,43 @@ class ShardedChebNet:
         if self.world > 1:
             all_reduce(stats, group=self.group)
         return stats[0], stats[1]
+
+
+class RowShardedChebNet(ShardedChebNet):
+    """The same ChebNet trained on the ROW partition: every rank holds its row block of the Laplacian only
+    (build_row_block), its rows of the features, and the halo rows it gathers.  A conv is K propagation orders with
+    their halo exchanges (_RowTermsFn), then the row-local weight GEMM over the orders side by side, bias and complex
+    ReLU; its backward is the Clenshaw sum over the same partition (Hermitian operator: same blocks, same plan).
+    Parameter gradients are summed over the ranks.  Memory per rank: the block's CSR and (n_local + n_halo) feature
+    rows per order — nothing of full height."""
+
+    def __init__(self, net, part):
+        from .layer.sparse_magnet import ChebConv, complex_relu_layer
+        self.net, self.part, self.n = net, part, part.n
+        self.rank, self.world, self.group = part.rank, part.world, part.group
+        self.rb = list(part.bounds)
+        self.r0, self.r1 = part.r0, part.r1
+        self.cache_input_propagation = False
+        mods = list(net.Chebs)
+        self.layers = []
+        i = 0
+        while i < len(mods):
+            assert isinstance(mods[i], ChebConv)
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], complex_relu_layer)
+            self.layers.append((mods[i], relu))
+            i += 2 if relu else 1
+
+    def trunk(self, x_rows):
+        from .layer.sparse_magnet import _ComplexReluFn
+        x = x_rows
+        rows_me = self.r1 - self.r0
+        for conv, relu in self.layers:
+            w, b = conv.weight, conv.bias
+            k1, cin, cout = w.shape
+            z = _RowTermsFn.apply(x, self.part, k1)                                  # [rows_me, 2, k1, cin]
+            out = torch.matmul(z.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
+            if b is not None:
+                out = out + b.reshape(1, 1, cout)
+            x = _ComplexReluFn.apply(out) if relu else out
+        return x
+

@@ -134,7 +134,7 @@ def test_column_bounds():
     assert b[0] == 0 and b[-1] == 5 and all(x <= y for x, y in zip(b, b[1:]))
 
 
-def _worker_train(rank, world, port, out_dir, layer, cached=False):
+def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -160,7 +160,10 @@ def _worker_train(rank, world, port, out_dir, layer, cached=False):
         g = torch.Generator().manual_seed(1)
         X = torch.randn(n, cin, generator=g); y = torch.randint(0, ncls, (1, n), generator=g)
         train = torch.rand(n, generator=g) < 0.5
-        sh = D.ShardedChebNet(net, op, n, rank, world)
+        if rows:            # the row partition: every rank holds its row block only
+            sh = D.RowShardedChebNet(net, D.RowPartition.from_global(rp, ci, val, n, rank, world, ScipyOperator))
+        else:
+            sh = D.ShardedChebNet(net, op, n, rank, world)
         sh.cache_input_propagation = cached
         r0, r1 = sh.r0, sh.r1
         xp = torch.stack([X[r0:r1], X[r0:r1]], dim=1)
@@ -177,9 +180,10 @@ def _worker_train(rank, world, port, out_dir, layer, cached=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,layer,cached', [(2, 2, False), (3, 3, False), (2, 2, True), (3, 1, True)])
-def test_sharded_chebnet_training_matches_single_process(world, layer, cached, tmp_path):
-    mp.spawn(_worker_train, args=(world, _free_port(), str(tmp_path), layer, cached), nprocs=world, join=True)
+@pytest.mark.parametrize('world,layer,cached,rows', [(2, 2, False, False), (3, 3, False, False), (2, 2, True, False), (3, 1, True, False),
+                                                     (2, 2, False, True), (3, 3, False, True)])
+def test_sharded_chebnet_training_matches_single_process(world, layer, cached, rows, tmp_path):
+    mp.spawn(_worker_train, args=(world, _free_port(), str(tmp_path), layer, cached, rows), nprocs=world, join=True)
     # single-process reference: the oracle's forward under autograd with the same initial weights
     import magnet_amd.layer.sparse_magnet as M
     from magnet_amd.utils.hermitian import ChebBasis

@@ -105,6 +105,76 @@ def test_ranks_sharing_one_gpu_match_the_single_gpu_result(world, weighted, tmp_
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+def _train_setup(dev):
+    g = torch.Generator().manual_seed(8)
+    cin, ncls = 6, 4
+    X = torch.randn(N, cin, generator=g).to(dev)
+    y = torch.randint(0, ncls, (1, N), generator=g).to(dev)
+    train = (torch.rand(N, generator=g) < 0.5).to(dev)
+    return cin, ncls, X, y, train
+
+
+def _worker_train(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from magnet_amd import dist as D
+        from magnet_amd.laplacian import MagneticLaplacian
+        from magnet_amd.layer.sparse_magnet import ChebNet
+        from magnet_amd.utils.hermitian import ChebBasis
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        blk, bounds = D.build_row_block(_chunks(dev, False), N, rank, world, q=0.2)
+        part = D.RowPartition(blk.row_ptr, blk.col_idx, blk.val, N, bounds, rank, world,
+                              lambda rp, ci, v, nc: MagneticLaplacian(rp, ci, v, nc))
+        cin, ncls, X, y, train = _train_setup(dev)
+        torch.manual_seed(0)
+        net = ChebNet(cin, ChebBasis(blk, 2), None, num_filter=8, K=2, label_dim=ncls, activation=True, layer=2).to(dev)
+        sh = D.RowShardedChebNet(net, part)
+        r0, r1 = sh.r0, sh.r1
+        xp = torch.stack([X[r0:r1], X[r0:r1]], dim=1).contiguous()
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
+        tr = train[r0:r1].nonzero().squeeze(1); va = (~train[r0:r1]).nonzero().squeeze(1)
+        losses = []
+        for _ in range(2):
+            tl, vl = sh.epoch(opt, xp, y[:, r0:r1].contiguous(), tr, va, int(train.sum()), int((~train).sum()))
+            losses.append((tl.item(), vl.item()))
+        torch.save({'losses': losses, 'state': {k: v.cpu() for k, v in net.state_dict().items()}}, os.path.join(out_dir, 't%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_partitioned_training_on_ranks_sharing_one_gpu(tmp_path):
+    """Two Adam epochs of a ChebNet over the ROW partition (every rank: its own row block, built by itself, compact
+    [own | halo] features, halo exchanges in forward and backward) by three processes on this GPU, against the same
+    epochs of the single-GPU network."""
+    world = 3
+    mp.spawn(_worker_train, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from magnet_amd.laplacian import build_magnetic_laplacian
+    from magnet_amd.layer.sparse_magnet import ChebNet
+    from magnet_amd.utils.hermitian import ChebBasis
+    from magnet_amd.train import node_epoch
+    dev = torch.device('cuda', 0)
+    parts = [torch.cat(t) for t in zip(*_chunks(dev, False)())]
+    L = build_magnetic_laplacian(parts[0], parts[1], N, q=0.2)
+    cin, ncls, X, y, train = _train_setup(dev)
+    torch.manual_seed(0)
+    net = ChebNet(cin, ChebBasis(L, 2), None, num_filter=8, K=2, label_dim=ncls, activation=True, layer=2).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
+    ref = []
+    for _ in range(2):
+        tl, _, vl, _ = node_epoch(net, opt, X, X, y, train.nonzero().squeeze(1), (~train).nonzero().squeeze(1))
+        ref.append((tl.item(), vl.item()))
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), 't%d.pt' % r))
+        for (a, b), (c, d) in zip(o['losses'], ref):
+            assert abs(a - c) <= 1e-5 * abs(c) and abs(b - d) <= 1e-5 * abs(d), (o['losses'], ref)
+        for k, v in net.state_dict().items():
+            assert float((o['state'][k].to(dev) - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+
+
 @pytest.mark.parametrize('strategy', ['rows', 'cols'])
 def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     """bench.py launched as the driver launches it for --gpus 2 (torch.distributed.run, one process per rank), both
