@@ -51,6 +51,9 @@ def parse_args():
                    help='apply a random vertex relabelling (seed 99) to the generated graph: the locality-free stress variant')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-epoch', action='store_true', help='skip the secondary epoch-time measurement')
+    p.add_argument('--epoch-layout', choices=['cols', 'rows'], default='cols',
+                   help='multi-GPU epoch leg: cols = ShardedChebNet (every rank holds the whole CSR), rows = RowShardedChebNet '
+                        '(every rank builds and holds its row block only, halo exchanges in forward and backward)')
     p.add_argument('--epoch-nodes', type=int, default=2_000_000, help='graph of the secondary epoch measurement (config 4)')
     p.add_argument('--epoch-edges', type=int, default=40_000_000)
     p.add_argument('--cpu-sample-nodes', type=int, default=250_000)
@@ -174,7 +177,7 @@ def cpu_baseline(args):
     }
 
 
-def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000):
+def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'):
     """Secondary metric: one training epoch (train forward + backward + Adam, then an evaluation
     forward: reference src/sparse_Magnet.py:143-176) of a 2-layer ChebNet, 128 -> 128 -> 128 filters,
     K = 2, q = 0.25, complex ReLU, 5 classes, on BASELINE.json config 4 (power-law digraph, 2M nodes /
@@ -196,8 +199,14 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000):
     y = torch.randint(0, ncls, (1, n), device=dev, generator=gen)
     train = torch.rand(n, device=dev, generator=gen) < 0.6
     if multi:
-        from magnet_amd.dist import ShardedChebNet
-        sh = ShardedChebNet(net, lap, n, rank, world)
+        from magnet_amd import dist as D
+        if layout == 'rows':
+            # the rank cuts its row block out of the CSR it has just built (bit-identical to building the block alone)
+            part = D.RowPartition.from_global(lap.row_ptr, lap.col_idx, lap.val, n, rank, world,
+                                              lambda rp, ci, v, nc: type(lap)(rp, ci, v, nc))
+            sh = D.RowShardedChebNet(net, part)
+        else:
+            sh = D.ShardedChebNet(net, lap, n, rank, world)
         r0, r1 = sh.r0, sh.r1
         xp = torch.stack([X[r0:r1], X[r0:r1]], dim=1).contiguous()
         yl = y[:, r0:r1].contiguous()
@@ -233,13 +242,13 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000):
     ChebConv.cache_input_propagation = False       # every forward recomputes T_k(L) X, as the reference does
     ms = timed()
     ChebConv.cache_input_propagation = True        # first layer's weight-independent T_k(L) X kept across forwards
-    if multi:
+    if multi and layout == 'cols':
         sh.cache_input_propagation = True
     ms_cached = timed()
     ChebConv.cache_input_propagation = False       # back to the default
     return {'ms': ms, 'ms_with_cached_input_propagation': ms_cached, 'n_gpus': world, 'nnz': lap.nnz,
             'config': 'config 4: power-law digraph N=%d E=%d, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
-                      'train fwd+bwd+Adam + eval fwd' % (n, e) + (', ShardedChebNet' if multi else '')}
+                      'train fwd+bwd+Adam + eval fwd' % (n, e) + ((', ShardedChebNet' if layout == 'cols' else ', RowShardedChebNet') if multi else '')}
 
 
 def edge_source(args, n, e, dev, chunk=50_000_000):
@@ -547,7 +556,7 @@ def main():
         torch.cuda.empty_cache()
         note(rank, 'epoch measurement (config 4)')
         try:
-            epoch = epoch_time(rank, world, dev, multi, args.epoch_nodes, args.epoch_edges)
+            epoch = epoch_time(rank, world, dev, multi, args.epoch_nodes, args.epoch_edges, args.epoch_layout)
         except Exception as ex:                         # the headline metric must still be reported
             epoch = {'error': repr(ex)[:300]}
         if out is not None:

@@ -186,7 +186,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
            '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy, '--no-cpu-baseline']
     # the column-sharded run also takes the secondary measurements: the same conv row-partitioned, and a training epoch
     # of the sharded ChebNet (on a small graph here)
-    cmd += ['--no-epoch'] if strategy == 'rows' else ['--epoch-nodes', '50000', '--epoch-edges', '1000000']
+    cmd += ['--epoch-nodes', '50000', '--epoch-edges', '1000000', '--epoch-layout', strategy]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=110)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
@@ -200,4 +200,5 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     assert 0 < m['row_layout']['largest_block_nnz'] < d['config']['nnz']
     if strategy == 'cols':
         assert d['row_partition']['ms_per_step'] > 0 and np.isfinite(d['row_partition']['exposed_comm_ms_per_step'])
-        assert d['epoch']['ms'] > 0 and d['epoch']['n_gpus'] == 2 and d['epoch']['ms_with_cached_input_propagation'] > 0
+    assert d['epoch']['ms'] > 0 and d['epoch']['n_gpus'] == 2 and d['epoch']['ms_with_cached_input_propagation'] > 0
+    assert ('RowShardedChebNet' in d['epoch']['config']) == (strategy == 'rows')
