@@ -68,6 +68,44 @@ def test_noalloc_entry_point_matches_planned_twice():
         assert np.abs(got - ref)[far].max() <= 1e-5 * np.abs(ref).max()
 
 
+def test_noalloc_entry_point_under_hip_graph_capture():
+    """What the entry point is for: a caller that may not allocate.  After one ordinary call on the device (which
+    resolves the built-in buffer's address), the operator is captured into a HIP graph and replayed on new inputs;
+    every replay equals the planned entry point run eagerly, and the capture itself allocates no device memory."""
+    import torch
+    from magnet_amd._lib import ops
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    lap, plan, n_long, n_chunks, chunk, x, z, bias = _case(40_000, 900_000, 64, 9, dev)
+    n, _, f = x.shape
+    y = torch.empty_like(x); mask = torch.empty((n, f), dtype=torch.uint8, device=dev)
+    call = lambda: ops.cspmm_noalloc(lap.row_ptr, lap.col_idx, lap.val, n, x, y, 2.0, z, -1.0, None, 0.0, bias, True, mask,
+                                     plan, n_long, n_chunks, chunk)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()                                    # first call on this device: outside any capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    def captured_bytes(body):                     # what a capture adds to torch's allocator (its own bookkeeping included)
+        graph = torch.cuda.CUDAGraph()
+        before = torch.cuda.memory_allocated(dev)
+        with torch.cuda.graph(graph):             # global capture mode: a hipMalloc in here would fail the capture
+            body()
+        return graph, torch.cuda.memory_allocated(dev) - before
+    idle, _ = captured_bytes(lambda: y.add_(0.0))     # holds the generator state torch sets up with a process's first graph
+    graph, used = captured_bytes(call)
+    assert used == 0
+    g = torch.Generator(device=dev).manual_seed(77)
+    for _ in range(3):
+        x.copy_(torch.randn(x.shape, device=dev, generator=g))
+        y.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = lap.spmm(x, alpha=2.0, z1=z, beta1=-1.0, bias=bias, relu=True, mask=torch.empty_like(mask))
+        assert torch.equal(y, want)
+
+
 def test_noalloc_entry_point_refuses_what_does_not_fit():
     import torch
     from magnet_amd import _lib
