@@ -658,6 +658,51 @@ def test_row_partition_operators_on_gpu(graph):
     assert float((out - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+def test_relabelled_graph_gives_the_same_orders_with_a_smaller_halo():
+    """magnet_amd.partition on the GPU: the parts found for a graph with hidden communities, turned into a vertex
+    order, shrink every rank's halo in the row partition, and the propagation orders computed on the renumbered
+    graph (four emulated ranks, blocks = parts) equal the single-GPU orders of the original numbering."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd import dist as D, partition as P
+    from test_host_logic import _planted_digraph
+    n, world, f, n_terms = 20000, 4, 32, 3
+    src, dst, _ = _planted_digraph(n, world, 8, 1, 3)
+    src, dst = src.to(DEV), dst.to(DEV)
+    parts_cpu = P.balanced_label_propagation(src.cpu(), dst.cpu(), n, world)
+    parts = P.balanced_label_propagation(src, dst, n, world)
+    assert torch.equal(parts.cpu(), parts_cpu)                                   # same decisions on either device
+    new_of_old, old_of_new, bounds = P.order_from_parts(parts, world)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    L2 = lap.build_magnetic_laplacian(new_of_old[src], new_of_old[dst], n, q=0.25)
+    assert L2.nnz == L.nnz
+    plain = _emulated_partitions(L, n, world, lap, D)
+    moved = _emulated_partitions(L2, n, world, lap, D, bounds=bounds)
+    assert max(p.n_halo for p in moved) < 0.6 * max(p.n_halo for p in plain)
+    x = _rand_packed(n, f, 11)
+    ref = [x, L.spmm(x)]
+    for k in range(2, n_terms):
+        ref.append(L.spmm(ref[k - 1], alpha=2.0, z1=ref[k - 2], beta1=-1.0))
+    x2 = x[old_of_new].contiguous()
+    zs = []
+    for p in moved:
+        b = p.new_buffer(f, DEV); b.fill_(float('nan')); p.block(b).copy_(x2[p.r0:p.r1])
+        zs.append([b])
+    _emulated_exchange(moved, [z[0] for z in zs], D)
+    for k in range(1, n_terms):
+        new = [torch.full((p.n_buf, 2, f), float('nan'), device=DEV) for p in moved]
+        for r, p in enumerate(moved):
+            if k == 1:
+                p.propagate(zs[r][0], new[r], 1.0)
+            else:
+                p.propagate(zs[r][k - 1], new[r], 2.0, zs[r][k - 2], -1.0)
+        _emulated_exchange(moved, new, D)
+        for r in range(world):
+            zs[r].append(new[r])
+    got2 = torch.cat([p.block(zs[r][-1]) for r, p in enumerate(moved)])         # renumbered order
+    got = got2[new_of_old]
+    assert float((got - ref[-1]).abs().max()) <= 1e-5 * float(ref[-1].abs().max())
+
+
 @pytest.mark.parametrize('case', ['unweighted', 'weighted', 'lambda3'])
 def test_row_blocks_built_per_rank_stack_to_the_full_laplacian(case):
     """Every rank builds only its own row block from the edges incident to it (mh_lap_block_*); the blocks of
