@@ -29,6 +29,14 @@ def _hash01(ids, salt):
     return x.to(torch.float64) / 4294967296.0
 
 
+def _sum_by(keys, values, n_keys):
+    """sum of `values` per key.  With a handful of keys an index_add_ would send every element's atomic to the same few
+    addresses (they serialise on a GPU); masked sums are reductions instead."""
+    if n_keys <= 16:
+        return torch.stack([(values * (keys == k)).sum() for k in range(n_keys)])
+    return torch.zeros(n_keys, dtype=values.dtype, device=values.device).index_add_(0, keys, values)
+
+
 def _propagate(a, b, weight, n, fracs, iters, slack, noise, damping, salt, init=None):
     """Size-constrained synchronous label propagation on the symmetric edge list (a, b): part p may carry at most
     slack * fracs[p] of the total vertex weight."""
@@ -55,11 +63,13 @@ def _propagate(a, b, weight, n, fracs, iters, slack, noise, damping, salt, init=
         here = votes.gather(1, part.unsqueeze(1)).squeeze(1)
         best_votes, best = votes.max(dim=1)
         wants = (best_votes > here) & (best != part)
-        load = torch.zeros(n_parts, dtype=torch.float64, device=dev).index_add_(0, part, weight)
+        load = _sum_by(part, weight, n_parts)
         # demand[p, q]: weight that wants to go from part p to part q
-        demand = torch.zeros(n_parts * n_parts, dtype=torch.float64, device=dev)
-        demand.index_add_(0, part[wants] * n_parts + best[wants], weight[wants])
-        demand = demand.view(n_parts, n_parts)
+        asking_w = torch.where(wants, weight, torch.zeros_like(weight))
+        if n_parts <= 4:
+            demand = _sum_by(part * n_parts + best, asking_w, n_parts * n_parts).view(n_parts, n_parts)
+        else:
+            demand = torch.stack([_sum_by(best, asking_w * (part == p), n_parts) for p in range(n_parts)])
         # admitted: what the opposite direction gives back (a swap leaves both loads as they were), plus a share of the
         # room the target has left
         room = (cap - load).clamp_(min=0.0)
