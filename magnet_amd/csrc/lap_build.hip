@@ -7,8 +7,13 @@
 //   1. every input edge (i, j, w) becomes two directed 64-bit records
 //        key = row << (cb+1) | col << 1 | dir       (cb = bits of n_nodes-1)
 //      (i, j, dir=0) "forward" and (j, i, dir=1) "backward";
-//   2. one stable LSD radix sort over the 2*cb+1 live key bits (radix_sort.hip: tile histograms,
-//      column scan, ballot-match ranking; duplicate edges keep their input order);
+//   2. one stable LSD radix sort over the 2*cb live (row, col) key bits (radix_sort.hip: tile histograms,
+//      column scan, ballot-match ranking; duplicate edges keep their input order).  Unweighted whole-graph
+//      builds whose column digits fill whole passes stop once after the column passes, when the records are
+//      grouped by column: the size of a column's group IS that node's record count (every record (i, j) has its
+//      mirror (j, i)), i.e. its degree, and it is written into the key's spare top bits on the way through the
+//      next pass ("tagged" keys) - the emission then computes d^-1/2 of an entry's column from the tag instead
+//      of gathering it from the degree table, the one access of the build that has no order;
 //   3. per (row, col) segment: w_fwd, w_bwd summed in fp32 in input order,
 //      s = (w_fwd + w_bwd)/2, delta = w_fwd - w_bwd, keep = (delta != 0 && s != 0);
 //   4. degrees d_row = sum_col s (fp64 over the row's records, or half the record count
@@ -39,6 +44,8 @@ using mhscan::scan_tiles;
 using mhscan::scan_tile_write;
 
 constexpr int kLongRun = 64;          // (row, col) runs longer than this are summed by a whole wavefront
+constexpr int kTagBits = 15;          // spare key bits that carry a column's record count (tagged keys)
+constexpr uint32_t kTagCap = (1u << kTagBits) - 1u;     // this value = "too many to fit: look the degree up"
 
 struct Header {          // first 256 bytes of the workspace
     int32_t err;         // bit 0: an endpoint outside [0, n_nodes); bit 1: a record outside the row block
@@ -89,6 +96,13 @@ Layout make_layout(int64_t m, int32_t n_nodes, bool weighted) {
     return L;
 }
 
+// Tagged keys (see the header): unweighted builds of the whole graph, when the column bits fill whole sort passes (so the
+// sort can stop between columns and rows at no extra pass) and the key has kTagBits spare bits.
+inline bool use_tags(const Layout& L, bool weighted, bool whole_graph) {
+    return whole_graph && !weighted && L.m > 0 && 2 * mhsort::passes_for(L.cb) == mhsort::passes_for(2 * L.cb) &&
+           2 * L.cb + 1 + kTagBits <= 64;
+}
+
 inline int64_t full_records(int64_t n_edges, int32_t n_nodes, bool gcn) {
     return 2 * (n_edges + (gcn ? int64_t(n_nodes) : 0));
 }
@@ -129,15 +143,17 @@ __global__ void __launch_bounds__(kBlock) make_records(const IdxT* __restrict__ 
 // per row (neighbouring rows end next to each other, so a wave's searches share their cache lines); cost
 // does not depend on how the records are spread over the rows.
 // ---------------------------------------------------------------------------
+// The same search finds the first record of every COLUMN while the records are ordered by column only (between the
+// column passes and the row passes of the sort): `shift` / `mask` select the field the records are ordered by.
 __global__ void __launch_bounds__(kBlock) row_starts(const uint64_t* __restrict__ keys, int64_t m, int32_t n_nodes,
-                                                     int cb, int32_t* __restrict__ rec_ptr) {
+                                                     int shift, uint64_t mask, int32_t* __restrict__ rec_ptr) {
     int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (r > n_nodes) return;
-    const uint64_t target = uint64_t(r) << (cb + 1);
+    const uint64_t target = uint64_t(r);
     int64_t lo = 0, hi = m;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        if (((keys[mid] >> shift) & mask) < target) lo = mid + 1; else hi = mid;
     }
     rec_ptr[r] = int32_t(lo);
 }
@@ -272,17 +288,22 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
                                                        const uint32_t* __restrict__ pos, const float* __restrict__ seg_s,
                                                        const float* __restrict__ seg_d, const float* __restrict__ dinv,
                                                        int64_t m, int cb, int32_t row_lo, float two_pi_q, float scale, int diag,
-                                                       int64_t nnz, int32_t* __restrict__ col_idx,
+                                                       int64_t nnz, int tagged, int32_t* __restrict__ col_idx,
                                                        float2* __restrict__ val) {
     int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= m || !flags[p]) return;
     uint64_t k = keys[p];
-    int32_t r = int32_t(k >> (cb + 1));
-    int32_t c = int32_t((k >> 1) & ((1ull << cb) - 1ull));
+    const uint64_t node_mask = (1ull << cb) - 1ull;
+    int32_t r = int32_t((k >> (cb + 1)) & node_mask);
+    int32_t c = int32_t((k >> 1) & node_mask);
     int64_t idx = int64_t(pos[p]);
     if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
     if (idx >= nnz) return;                            // caller's arrays are shorter than the count phase reported
-    float a = (dinv[r] * seg_s[p]) * dinv[c];          // (D A_s) D, hermitian.py:154
+    float dc;
+    const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
+    if (tag < kTagCap) dc = inv_sqrt_degree(double(tag));     // the column's record count travelled in the key
+    else dc = dinv[c];
+    float a = (dinv[r] * seg_s[p]) * dc;               // (D A_s) D, hermitian.py:154
     float theta = two_pi_q * seg_d[p];                 // fp32 product, hermitian.py:157
     float sn, cs;
     sincosf(theta, &sn, &cs);                          // full-range accurate sincos, hermitian.py:158
@@ -298,10 +319,11 @@ __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restri
     int64_t r = int64_t(row_lo) + int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (r >= row_hi) return;
     uint64_t target = (uint64_t(r) << (cb + 1)) | (uint64_t(r) << 1);
+    const uint64_t live = (1ull << (2 * cb + 1)) - 1ull;   // (row, col, dir): tagged keys carry a count above these bits
     int64_t lo = 0, hi = m;                             // lower_bound(keys, target)
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        if ((keys[mid] & live) < target) lo = mid + 1; else hi = mid;
     }
     int64_t idx = int64_t(pos[lo]) + (r - row_lo);
     if (idx >= nnz) return;
@@ -342,7 +364,7 @@ struct EdgeList { const void* row; const void* col; const float* w; int64_t n; i
 // An odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1,
 // so that the sorted records always end in keys1 / w1.
 int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const EdgeList& bwd, int idx64, bool weighted,
-                     int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream) {
+                     bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream) {
     const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
     uint64_t* rec_keys = start_in_0 ? W.keys0 : W.keys1;
     float* rec_w = weighted ? (start_in_0 ? W.w0 : W.w1) : nullptr;
@@ -366,7 +388,19 @@ int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const 
     if (L.m > 0) {
         uint64_t* other = rec_keys == W.keys0 ? W.keys1 : W.keys0;
         float* other_w = weighted ? (rec_w == W.w0 ? W.w1 : W.w0) : nullptr;
-        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, W.sort, L.sort_bytes, stream));
+        if (!tagged) {
+            MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, W.sort, L.sort_bytes, stream));
+        } else {
+            // column passes; group sizes of the columns; row passes, the first of which writes the sizes into the keys
+            const uint64_t node_mask = (1ull << L.cb) - 1ull;
+            MH_HIP(mhsort::sort(rec_keys, other, nullptr, nullptr, L.m, 1, L.cb, W.sort, L.sort_bytes, stream));
+            uint64_t* by_col = (mhsort::passes_for(L.cb) & 1) ? other : rec_keys;
+            uint64_t* spare = by_col == rec_keys ? other : rec_keys;
+            row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(by_col, L.m, n_nodes, 1, node_mask, W.rec_ptr);
+            MH_LAUNCH_CHECK("column_starts");
+            const mhsort::Tag tag{W.rec_ptr, 1, uint32_t(node_mask), 2 * L.cb + 1, kTagCap};
+            MH_HIP(mhsort::sort(by_col, spare, nullptr, nullptr, L.m, L.cb + 1, L.cb, W.sort, L.sort_bytes, stream, &tag));
+        }
     }
     return MH_OK;
 }
@@ -374,7 +408,8 @@ int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const 
 // everything of the count phase after the sort; rows [row_lo, row_hi) are the rows the records belong to
 int count_sorted(const Layout& L, const Work& W, bool weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, int diag,
                  int32_t* row_ptr, float* dinv_block, int64_t* nnz_host, hipStream_t stream) {
-    row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb, W.rec_ptr);
+    row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb + 1, (1ull << L.cb) - 1ull,
+                                                                      W.rec_ptr);
     MH_LAUNCH_CHECK("row_starts");
     if (n_nodes > 0) {
         if (weighted)
@@ -410,8 +445,8 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, int32_t n_nodes,
     return MH_OK;
 }
 
-int fill_sorted(const Layout& L, const Work& W, int32_t row_lo, int32_t row_hi, double q, double max_eigen, int64_t nnz,
-                const float* dinv, int32_t* col_idx, float* val, hipStream_t stream) {
+int fill_sorted(const Layout& L, const Work& W, bool tagged, int32_t row_lo, int32_t row_hi, double q, double max_eigen,
+                int64_t nnz, const float* dinv, int32_t* col_idx, float* val, hipStream_t stream) {
     const float* seg_s = reinterpret_cast<const float*>(W.keys0);
     const float* seg_d = seg_s + L.m_pad;
     const float scale = float(2.0 / max_eigen);                 // the double quotient rounded once (hermitian.py:167)
@@ -424,7 +459,8 @@ int fill_sorted(const Layout& L, const Work& W, int32_t row_lo, int32_t row_hi, 
         MH_REQUIRE(col_idx && val, "col_idx/val is null");
         MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
         emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.flags, W.pos, seg_s, seg_d, dinv, L.m, L.cb, row_lo,
-                                                           two_pi_q, scale, diag, nnz, col_idx, reinterpret_cast<float2*>(val));
+                                                           two_pi_q, scale, diag, nnz, tagged ? 1 : 0, col_idx,
+                                                           reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_entries");
     }
     if (diag && row_hi > row_lo) {
@@ -469,7 +505,7 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
     if (rc != MH_OK) return rc;
     const int diag = (float(2.0 / max_eigen) * 1.0f - 1.0f) != 0.0f;
     EdgeList e{row, col, weight, n_edges, gcn ? int64_t(n_nodes) : 0};
-    rc = records_and_sort(L, W, e, e, idx64, weighted, n_nodes, 0, n_nodes, stream);
+    rc = records_and_sort(L, W, e, e, idx64, weighted, use_tags(L, weighted, true), n_nodes, 0, n_nodes, stream);
     if (rc != MH_OK) return rc;
     return count_sorted(L, W, weighted, n_nodes, 0, n_nodes, diag, row_ptr, nullptr, nnz_host, stream);
 }
@@ -486,7 +522,7 @@ extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, dou
     if (workspace_bytes < L.total)
         return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
     Work W = cut(workspace, L, weighted);
-    int rc = fill_sorted(L, W, 0, n_nodes, q, max_eigen, nnz, W.dinv, col_idx, val, stream);
+    int rc = fill_sorted(L, W, use_tags(L, weighted, true), 0, n_nodes, q, max_eigen, nnz, W.dinv, col_idx, val, stream);
     if (rc != MH_OK) return rc;
     if (dinv_out && n_nodes > 0)
         MH_HIP(hipMemcpyAsync(dinv_out, W.dinv, size_t(n_nodes) * 4, hipMemcpyDeviceToDevice, stream));
@@ -518,7 +554,7 @@ extern "C" int mh_lap_block_count(const void* fwd_row, const void* fwd_col, cons
     if (rc != MH_OK) return rc;
     const int diag = (float(2.0 / max_eigen) * 1.0f - 1.0f) != 0.0f;
     EdgeList f{fwd_row, fwd_col, fwd_w, n_fwd, 0}, b{bwd_row, bwd_col, bwd_w, n_bwd, 0};
-    rc = records_and_sort(L, W, f, b, idx64, weighted, n_nodes, row_lo, row_hi, stream);
+    rc = records_and_sort(L, W, f, b, idx64, weighted, false, n_nodes, row_lo, row_hi, stream);
     if (rc != MH_OK) return rc;
     return count_sorted(L, W, weighted, n_nodes, row_lo, row_hi, diag, row_ptr_block, dinv_block, nnz_host, stream);
 }
@@ -536,5 +572,5 @@ extern "C" int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, 
     if (workspace_bytes < L.total)
         return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
     Work W = cut(workspace, L, weighted);
-    return fill_sorted(L, W, row_lo, row_hi, q, max_eigen, nnz, dinv_full, col_idx, val, stream);
+    return fill_sorted(L, W, false, row_lo, row_hi, q, max_eigen, nnz, dinv_full, col_idx, val, stream);
 }

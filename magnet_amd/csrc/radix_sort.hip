@@ -93,10 +93,10 @@ __global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist,
     }
 }
 
-template <bool PAIRS>
+template <bool PAIRS, bool TAG>
 __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                     const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
-                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs) {
+                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag) {
     __shared__ uint32_t cnt[kWaves][kBins];
     __shared__ uint32_t digit_start[kBins];
     __shared__ uint32_t goff[kBins];
@@ -119,6 +119,12 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
         bool ok = idx < n;
         key[i] = ok ? kin[idx] : ~0ull;
         if (PAIRS) val[i] = ok ? vin[idx] : 0.f;
+        if (TAG && ok) {
+            // the keys arrive grouped by the field, so neighbouring lanes read the same few entries of starts[]
+            const uint32_t f = uint32_t(key[i] >> tag.field_shift) & tag.field_mask;
+            const uint32_t cnt = uint32_t(tag.starts[f + 1] - tag.starts[f]);
+            key[i] |= uint64_t(cnt < tag.cap ? cnt : tag.cap) << tag.tag_shift;
+        }
     }
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -195,8 +201,9 @@ size_t workspace_bytes(int64_t n) {
 }
 
 hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int first_bit, int bits, void* workspace,
-                size_t ws_bytes, hipStream_t stream) {
+                size_t ws_bytes, hipStream_t stream, const Tag* tag) {
     if (n <= 0 || bits <= 0) return hipSuccess;
+    if (tag && va) return hipErrorInvalidValue;
     if (ws_bytes < workspace_bytes(n) || n >= (int64_t(1) << 32)) return hipErrorInvalidValue;
     const int64_t tiles = (n + kTile - 1) / kTile;
     const int64_t chunks = (tiles + kChunk - 1) / kChunk;
@@ -214,8 +221,9 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
         scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
         scan_chunks<<<1, kBins, 0, stream>>>(chunk, chunks);
         scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
-        if (pairs) scatter<true><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist);
-        else scatter<false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist);
+        if (pairs) scatter<true, false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, Tag{});
+        else if (tag && done == 0) scatter<false, true><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist, *tag);
+        else scatter<false, false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist, Tag{});
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         uint64_t* t = a; a = b; b = t;

@@ -1116,7 +1116,8 @@ def test_recursion_entry_points_and_row_staging(small_graph):
         assert torch.equal(tgt[idx.long()], x[idx.long()]) and int((tgt.abs().sum((1, 2)) > 0).sum()) == 777
 
 
-@pytest.mark.parametrize('case', ['signed_weights', 'many_duplicates', 'pow2_nodes', 'pow2_plus_one', 'two_nodes', 'dense_small'])
+@pytest.mark.parametrize('case', ['signed_weights', 'many_duplicates', 'pow2_nodes', 'pow2_plus_one', 'two_nodes', 'dense_small',
+                                  'huge_hub', 'huge_hub_self_loops'])
 def test_builder_edge_cases_vs_oracle(case):
     _, lap, H, _, O = _mods()
     rng = np.random.default_rng(17)
@@ -1138,6 +1139,12 @@ def test_builder_edge_cases_vs_oracle(case):
     elif case == 'two_nodes':
         n = 2
         r = np.array([0, 0, 1]); c = np.array([1, 1, 0])
+    elif case.startswith('huge_hub'):
+        # unweighted, 15 node bits: the builder carries every column's record count in spare key bits, and node 5 has
+        # more records (40 000 + 30 000) than those bits hold, so its entries take the table look-up instead
+        n, e = 20000, 150000
+        r = np.concatenate([rng.integers(0, n, e), np.full(40000, 5), rng.integers(0, n, 30000)])
+        c = np.concatenate([rng.integers(0, n, e), rng.integers(0, n, 40000), np.full(30000, 5)])
     else:                                 # every ordered pair present once or twice
         n = 60
         r, c = np.nonzero(rng.random((n, n)) < 0.7)
@@ -1146,8 +1153,9 @@ def test_builder_edge_cases_vs_oracle(case):
         # keep degrees positive by construction so the comparison is meaningful
         w = np.abs(w) * np.where(rng.random(len(w)) < 0.5, 1.0, 2.0).astype(np.float32)
         w[::7] = 0.0                      # zero weights: delta == 0 and s == 0 pairs that must vanish
-    L = H.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w)
-    Lo = O.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w)
+    gcn = case == 'huge_hub_self_loops'
+    L = H.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w, gcn_appr=gcn)
+    Lo = O.hermitian_decomp_sparse(r, c, n, 0.15, edge_weight=w, gcn_appr=gcn)
     _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=3e-6, what=case)
 
 
