@@ -81,8 +81,9 @@ def builder_bytes(e, n, nnz, passes):
     records (read row, col int32 twice, write m keys), `passes` radix passes (histogram read + scatter read +
     write), row starts / degrees (about one more read of the keys' row part is cached; counted as N words),
     segments (keys read, s, delta and flag written), flag scan (flags read twice, slots written), emission
-    (keys, flags, slots, s, delta read; 12 bytes per nonzero written).  Random 4-byte reads of d^-1/2 (one per
-    nonzero) are not counted."""
+    (keys, flags, slots, s, delta read; 12 bytes per nonzero written).  d^-1/2 of an entry's column is computed from the
+    record count the key carries (unweighted whole-graph builds with whole column passes; a random 4-byte read per
+    nonzero otherwise, not counted); the search for the columns' group starts adds N words."""
     m = 2 * e
     return (2 * 8 * e + 8 * m) + passes * 24 * m + 8 * n + (8 * m + 8 * m + m) + (2 * m + 4 * m) + (8 * m + m + 4 * m + 8 * m + 12 * nnz)
 
@@ -497,7 +498,7 @@ def main():
                 'achieved': b_bytes / (build_device_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': b_bytes / (build_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'note': 'streamed bytes of all builder kernels (bench.py: builder_bytes) / HIP-event time of the whole build; '
-                        'the random d^-1/2 reads of the emission are not in the model'},
+                        'd^-1/2 of the columns comes from counts carried in the keys on this workload (no random reads)'},
             'multi_gpu': dist_info,
             'device': {'name': torch.cuda.get_device_properties(dev).name, 'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', '')),
                        'hbm_gb': torch.cuda.get_device_properties(dev).total_memory / 1e9},
