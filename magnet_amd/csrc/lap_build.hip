@@ -406,11 +406,15 @@ int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const 
 }
 
 // everything of the count phase after the sort; rows [row_lo, row_hi) are the rows the records belong to
-int count_sorted(const Layout& L, const Work& W, bool weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, int diag,
-                 int32_t* row_ptr, float* dinv_block, int64_t* nnz_host, hipStream_t stream) {
-    row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb + 1, (1ull << L.cb) - 1ull,
-                                                                      W.rec_ptr);
-    MH_LAUNCH_CHECK("row_starts");
+int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi,
+                 int diag, int32_t* row_ptr, float* dinv_block, int64_t* nnz_host, hipStream_t stream) {
+    // A tagged build has the row starts already: they are the column starts found between the sort's column and row
+    // passes (node j has as many records in row j as in column j, so both are the same running sum).
+    if (!tagged) {
+        row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb + 1, (1ull << L.cb) - 1ull,
+                                                                          W.rec_ptr);
+        MH_LAUNCH_CHECK("row_starts");
+    }
     if (n_nodes > 0) {
         if (weighted)
             degree_inv_sqrt_weighted<<<grid_for(int64_t(n_nodes) * 64), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
@@ -507,7 +511,7 @@ extern "C" int mh_lap_build_count(const void* row, const void* col, int idx64, c
     EdgeList e{row, col, weight, n_edges, gcn ? int64_t(n_nodes) : 0};
     rc = records_and_sort(L, W, e, e, idx64, weighted, use_tags(L, weighted, true), n_nodes, 0, n_nodes, stream);
     if (rc != MH_OK) return rc;
-    return count_sorted(L, W, weighted, n_nodes, 0, n_nodes, diag, row_ptr, nullptr, nnz_host, stream);
+    return count_sorted(L, W, weighted, use_tags(L, weighted, true), n_nodes, 0, n_nodes, diag, row_ptr, nullptr, nnz_host, stream);
 }
 
 extern "C" int mh_lap_build_fill(int64_t n_edges, int32_t n_nodes, double q, double max_eigen, int weighted_,
@@ -556,7 +560,7 @@ extern "C" int mh_lap_block_count(const void* fwd_row, const void* fwd_col, cons
     EdgeList f{fwd_row, fwd_col, fwd_w, n_fwd, 0}, b{bwd_row, bwd_col, bwd_w, n_bwd, 0};
     rc = records_and_sort(L, W, f, b, idx64, weighted, false, n_nodes, row_lo, row_hi, stream);
     if (rc != MH_OK) return rc;
-    return count_sorted(L, W, weighted, n_nodes, row_lo, row_hi, diag, row_ptr_block, dinv_block, nnz_host, stream);
+    return count_sorted(L, W, weighted, false, n_nodes, row_lo, row_hi, diag, row_ptr_block, dinv_block, nnz_host, stream);
 }
 
 extern "C" int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double q,
