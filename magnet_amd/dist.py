@@ -236,7 +236,8 @@ class RowPartition:
     first the rank's own rows, then its halo — the remote rows its block references, ascending by global id
     and therefore grouped by owning rank.  The block's columns are renumbered to that buffer (mh_halo_plan_*:
     own column c -> c - r0, remote c -> n_local + slot), and split into L_int (own columns: operands local)
-    and L_ext (halo columns).  `make_operator(rp, ci, val, n_cols)` turns CSR tensors into an object with
+    and L_ext (halo columns, numbered from the start of the halo: its operand is the halo part alone, which
+    may live in the same buffer behind the own rows or in a tensor of its own).  `make_operator(rp, ci, val, n_cols)` turns CSR tensors into an object with
     .spmm(X, out=, alpha=, z1=, beta1=) — the HIP MagneticLaplacian in production.
 
     Exchange of an order: every peer p gets the rows of this rank it references (`give[p]`, learned from p's
@@ -263,8 +264,8 @@ class RowPartition:
         self.n_halo = int(halo_ids.numel())
         self.n_buf = self.n_local + self.n_halo
         (rpi, cii, vi), (rpe, cie, ve) = split_columns(rp_blk, col_local, val_blk, 0, self.n_local)
-        self.L_int = make_operator(rpi, cii, vi, self.n_buf)
-        self.L_ext = make_operator(rpe, cie, ve, self.n_buf)
+        self.L_int = make_operator(rpi, cii, vi, self.n_local)
+        self.L_ext = make_operator(rpe, (cie - self.n_local).to(cie.dtype), ve, self.n_halo)
         # tell every peer which of its rows this rank gathers (as row numbers inside the peer's block)
         self.need = [None if p == rank else (halo_ids[self.peer_ptr[p]:self.peer_ptr[p + 1]] - b[p]).to(torch.int32)
                      for p in range(world)]
@@ -293,6 +294,12 @@ class RowPartition:
     def exchange(self, buf):
         """Start sending the peers their halo rows of buf's own block and receiving this rank's halo.
         Returns a handle for finish_exchange()."""
+        return self.exchange_split(buf[:self.n_local], buf[self.n_local:])
+
+    def exchange_split(self, own, halo):
+        """The same exchange with the two parts given separately: `own` [n_local, 2, F] (any row stride: e.g. one
+        order of a side-by-side block) is what the peers are served from, `halo` [n_halo, 2, F] (contiguous) is
+        where this rank's halo rows arrive."""
         if self.world == 1 or not self.comm_enabled:
             return None
         ops, staged = [], []
@@ -301,11 +308,12 @@ class RowPartition:
             to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
             g = self.give[to]
             if g.numel():
-                mine = buf[:nl] if g.numel() == nl else self.mover.gather(buf, g)   # ascending + complete = the block itself
+                # ascending + complete = the block itself: sent in place when it is contiguous
+                mine = own if (g.numel() == nl and own.is_contiguous()) else self.mover.gather(own, g)
                 ops.append(('send', mine, to))
                 staged.append(mine)                                  # keep the send buffer alive
             if pp[frm + 1] > pp[frm]:
-                ops.append(('recv', buf[nl + pp[frm]:nl + pp[frm + 1]], frm))
+                ops.append(('recv', halo[pp[frm]:pp[frm + 1]], frm))
         return (start_transfers(ops, self.group), staged)
 
     def finish_exchange(self, handle):
@@ -316,13 +324,38 @@ class RowPartition:
         """z_out[own] = alpha * (L z_prev)[own] + beta * z_prev2[own] (+ add_beta * add, a matrix of the rank's own
         rows).  `pending` is the handle of the exchange that completes z_prev's halo; only the halo-column part
         waits for it."""
-        blk = self.block(z_out)
-        self.L_int.spmm(z_prev, out=blk, alpha=alpha, z1=None if z_prev2 is None else self.block(z_prev2), beta1=beta,
+        nl = self.n_local
+        return self.propagate_split(z_prev[:nl], z_prev[nl:], z_out[:nl], alpha, None if z_prev2 is None else z_prev2[:nl],
+                                    beta, pending, add, add_beta)
+
+    def propagate_split(self, prev_own, prev_halo, out_own, alpha=1.0, prev2_own=None, beta=0.0, pending=None, add=None,
+                        add_beta=1.0):
+        """propagate() on operands given as (own rows, halo rows) pairs; the own-row matrices may be strided views."""
+        self.L_int.spmm(prev_own, out=out_own, alpha=alpha, z1=prev2_own, beta1=beta,
                         z2=add, beta2=add_beta if add is not None else 0.0)
         self.finish_exchange(pending)
         if self.n_halo:
-            self.L_ext.spmm(z_prev, out=blk, alpha=alpha, z1=blk, beta1=1.0)
-        return blk
+            self.L_ext.spmm(prev_halo, out=out_own, alpha=alpha, z1=out_own, beta1=1.0)
+        return out_own
+
+    def cheb_block(self, block, halos=None, halo_valid=False):
+        """Fills block[:, :, k] = own rows of T_k(L) x for k >= 1, given block [n_local, 2, n_terms, F] (contiguous)
+        whose order 0 holds the rank's rows of x: the orders side by side, the layout the weight GEMM reads in one
+        go.  The halo rows of the orders live in `halos` (n_terms - 1 contiguous [n_halo, 2, F] tensors, made here
+        when not given): they arrive there straight from the peers, and only the halo-column part of the operator
+        reads them.  `halo_valid`: halos[0] already holds x's halo."""
+        n_terms, f = block.size(2), block.size(3)
+        if halos is None:
+            halos = [torch.empty((self.n_halo, 2, f), dtype=block.dtype, device=block.device) for _ in range(max(n_terms - 1, 0))]
+        order = lambda k: block[:, :, k, :]
+        pending = None if (halo_valid or n_terms < 2) else self.exchange_split(order(0), halos[0])
+        for k in range(1, n_terms):
+            if k == 1:
+                self.propagate_split(order(0), halos[0], order(1), 1.0, pending=pending)
+            else:
+                self.propagate_split(order(k - 1), halos[k - 1], order(k), 2.0, order(k - 2), -1.0, pending=pending)
+            pending = self.exchange_split(order(k), halos[k]) if k < n_terms - 1 else None
+        return block
 
     def cheb_terms(self, x_buf, n_terms, buffers=None, halo_valid=False):
         """[T_0 x, ..., T_{n-1} x] as compact buffers whose own rows are valid (and, for all but the last
@@ -367,12 +400,11 @@ class _RowTermsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_own, part, n_terms):
-        f, dev = x_own.size(2), x_own.device
-        x_buf = part.new_buffer(f, dev)
-        part.block(x_buf).copy_(x_own)
-        zs = part.cheb_terms(x_buf, n_terms)
+        block = torch.empty((part.n_local, 2, n_terms, x_own.size(2)), dtype=x_own.dtype, device=x_own.device)
+        block[:, :, 0, :].copy_(x_own)
+        part.cheb_block(block)
         ctx.part = part
-        return torch.stack([part.block(z) for z in zs], dim=2)
+        return block
 
     @staticmethod
     def backward(ctx, dz):
@@ -460,21 +492,19 @@ class RowPartitionedConv:
         self.bias = torch.zeros(1, out_c, device=device)
         part = self.part
         gen = torch.Generator(device=device).manual_seed(seed + 1000 * rank)
-        self.x = part.new_buffer(in_c, device)
-        part.block(self.x).copy_(torch.randn(part.n_local, 2, in_c, device=device, generator=gen))
-        self.x[part.n_local:].zero_()
-        self.buffers = [part.new_buffer(in_c, device) for _ in range(K)]
+        # the rank's rows of the input and of the K orders side by side (one GEMM reads them), halo rows per order
+        self.block = torch.empty((part.n_local, 2, K + 1, in_c), device=device)
+        self.x = self.block[:, :, 0, :]
+        self.x.copy_(torch.randn(part.n_local, 2, in_c, device=device, generator=gen))
+        self.halos = [torch.zeros((part.n_halo, 2, in_c), device=device) for _ in range(K)]
         self.launches = []
 
     def step(self):
         part = self.part
-        zs = part.cheb_terms(self.x, self.K + 1, self.buffers)
-        rows = part.n_local
-        blk = lambda z: part.block(z).reshape(rows * 2, z.size(2))
-        out = torch.addmm(self.bias, blk(zs[0]), self.weight[0])
-        for k in range(1, self.K + 1):
-            out.addmm_(blk(zs[k]), self.weight[k])
-        return out.view(rows, 2, -1)
+        part.cheb_block(self.block, self.halos)
+        rows, (k1, cin, cout) = part.n_local, self.weight.shape
+        out = torch.addmm(self.bias, self.block.view(rows * 2, k1 * cin), self.weight.view(k1 * cin, cout))
+        return out.view(rows, 2, cout)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -834,9 +864,8 @@ class RowShardedChebNet(ShardedChebNet):
             w, b = conv.weight, conv.bias
             k1, cin, cout = w.shape
             z = _RowTermsFn.apply(x, self.part, k1)                                  # [rows_me, 2, k1, cin]
-            out = torch.matmul(z.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
-            if b is not None:
-                out = out + b.reshape(1, 1, cout)
+            zf, wf = z.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)
+            out = (torch.addmm(b.reshape(1, cout), zf, wf) if b is not None else torch.matmul(zf, wf)).view(rows_me, 2, cout)
             x = _ComplexReluFn.apply(out) if relu else out
         return x
 
