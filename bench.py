@@ -243,7 +243,7 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
     ChebConv.cache_input_propagation = False       # every forward recomputes T_k(L) X, as the reference does
     ms = timed()
     ChebConv.cache_input_propagation = True        # first layer's weight-independent T_k(L) X kept across forwards
-    if multi and layout == 'cols':
+    if multi:
         sh.cache_input_propagation = True
     ms_cached = timed()
     ChebConv.cache_input_propagation = False       # back to the default

@@ -683,12 +683,14 @@ def _regroup(x, src_bounds, dst_bounds, rank, world, group, to_cols):
     src_bounds / dst_bounds are (row bounds, column bounds)."""
     rb, cb = src_bounds, dst_bounds
     if to_cols:
-        send = [x[..., cb[p]:cb[p + 1]].contiguous() for p in range(world)]
-        recv = [send[p] if p == rank else
-                torch.empty((rb[p + 1] - rb[p],) + tuple(x.shape[1:-1]) + (cb[rank + 1] - cb[rank],), dtype=x.dtype, device=x.device)
-                for p in range(world)]
+        # every peer's rows of my columns arrive in their row range of the result (row ranges are contiguous)
+        out = torch.empty((rb[-1],) + tuple(x.shape[1:-1]) + (cb[rank + 1] - cb[rank],), dtype=x.dtype, device=x.device)
+        send = [None if p == rank else x[..., cb[p]:cb[p + 1]].contiguous() for p in range(world)]
+        recv = [out[rb[p]:rb[p + 1]] for p in range(world)]
+        recv[rank].copy_(x[..., cb[rank]:cb[rank + 1]])
+        send[rank] = recv[rank]
         wait_all(all_to_all_blocks(send, recv, rank, world, group))
-        return torch.cat(recv, dim=0)
+        return out
     send = [x[rb[p]:rb[p + 1]].contiguous() for p in range(world)]
     recv = [send[p] if p == rank else
             torch.empty((rb[rank + 1] - rb[rank],) + tuple(x.shape[1:-1]) + (cb[p + 1] - cb[p],), dtype=x.dtype, device=x.device)
@@ -754,21 +756,27 @@ class ShardedChebNet:
         rows_me = self.r1 - self.r0
         layers = self.layers
         conv0, relu0 = layers[0]
-        if (self.cache_input_propagation and not x_rows.requires_grad and conv0.weight.size(1) >= self.world):
+        if not x_rows.requires_grad and conv0.weight.size(1) >= self.world:
+            # An input that needs no gradient (the node features): its propagated orders T_k(L) X are constants of the
+            # step.  They are computed on column slices (one all-to-all of X there, one of the K+1 orders back) and the
+            # layer is the row-local GEMM on them; the weight gradient is then a product with these saved orders,
+            # where the GEMM-first form below would need K more SpMMs in backward for T_k(L) dOut.  Same number of
+            # orders on the wire per training step as the GEMM-first form (whose all-to-all also runs in backward).
             from .layer.sparse_magnet import _cheb_terms
             w, b = conv0.weight, conv0.bias
             k1, cin, cout = w.shape
-            c = self._input_cache
+            c = self._input_cache if self.cache_input_propagation else None
             if c is None or c[0] is not x_rows or c[1] != x_rows._version or c[3] != k1:
                 with torch.no_grad():
                     cb = column_bounds(cin, self.world)
                     xc = _regroup(x_rows.unsqueeze(2), self.rb, cb, self.rank, self.world, self.group, True).squeeze(2)
                     z = _cheb_terms(self.op, xc, k1)                                   # [N, 2, k1, my columns]
                     r = _regroup(z, self.rb, cb, self.rank, self.world, self.group, False)   # [rows_me, 2, k1, C_in]
-                c = self._input_cache = (x_rows, x_rows._version, r, k1)
-            out = torch.matmul(c[2].reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
-            if b is not None:
-                out = out + b.reshape(1, 1, cout)
+                c = (x_rows, x_rows._version, r, k1)
+                if self.cache_input_propagation:
+                    self._input_cache = c
+            rf, wf = c[2].reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)
+            out = (torch.addmm(b.reshape(1, cout), rf, wf) if b is not None else torch.matmul(rf, wf)).view(rows_me, 2, cout)
             x = _ComplexReluFn.apply(out) if relu0 else out
             layers = layers[1:]
         for conv, relu in layers:
@@ -847,6 +855,7 @@ class RowShardedChebNet(ShardedChebNet):
         self.rb = list(part.bounds)
         self.r0, self.r1 = part.r0, part.r1
         self.cache_input_propagation = False
+        self._input_cache = None
         mods = list(net.Chebs)
         self.layers = []
         i = 0
@@ -860,10 +869,19 @@ class RowShardedChebNet(ShardedChebNet):
         from .layer.sparse_magnet import _ComplexReluFn
         x = x_rows
         rows_me = self.r1 - self.r0
-        for conv, relu in self.layers:
+        for i, (conv, relu) in enumerate(self.layers):
             w, b = conv.weight, conv.bias
             k1, cin, cout = w.shape
-            z = _RowTermsFn.apply(x, self.part, k1)                                  # [rows_me, 2, k1, cin]
+            if i == 0 and self.cache_input_propagation and not x.requires_grad:
+                # the propagated orders of an input that needs no gradient do not depend on any weight: kept for as
+                # long as the same, unmodified tensor is passed (no SpMM and no exchange in this layer afterwards)
+                c = self._input_cache
+                if c is None or c[0] is not x or c[1] != x._version or c[3] != k1:
+                    with torch.no_grad():
+                        c = self._input_cache = (x, x._version, _RowTermsFn.apply(x, self.part, k1), k1)
+                z = c[2]
+            else:
+                z = _RowTermsFn.apply(x, self.part, k1)                              # [rows_me, 2, k1, cin]
             zf, wf = z.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)
             out = (torch.addmm(b.reshape(1, cout), zf, wf) if b is not None else torch.matmul(zf, wf)).view(rows_me, 2, cout)
             x = _ComplexReluFn.apply(out) if relu else out

@@ -181,7 +181,7 @@ def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False):
 
 
 @pytest.mark.parametrize('world,layer,cached,rows', [(2, 2, False, False), (3, 3, False, False), (2, 2, True, False), (3, 1, True, False),
-                                                     (2, 2, False, True), (3, 3, False, True)])
+                                                     (2, 2, False, True), (3, 3, False, True), (2, 2, True, True)])
 def test_sharded_chebnet_training_matches_single_process(world, layer, cached, rows, tmp_path):
     mp.spawn(_worker_train, args=(world, _free_port(), str(tmp_path), layer, cached, rows), nprocs=world, join=True)
     # single-process reference: the oracle's forward under autograd with the same initial weights

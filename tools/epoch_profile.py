@@ -12,6 +12,8 @@ def main():
     p.add_argument('--edges', type=int, default=40_000_000)
     p.add_argument('--epochs', type=int, default=5)
     p.add_argument('--cached', action='store_true')
+    p.add_argument('--layout', choices=['single', 'cols', 'rows'], default='single',
+                   help='cols / rows: the multi-GPU networks (ShardedChebNet / RowShardedChebNet) with one rank')
     a = p.parse_args()
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges
     from magnet_amd.layer.sparse_magnet import ChebNet, ChebConv
@@ -31,14 +33,28 @@ def main():
     train = torch.rand(n, device=dev, generator=gen) < 0.6
     tr = train.nonzero().squeeze(1); va = (~train).nonzero().squeeze(1)
     ChebConv.cache_input_propagation = a.cached
+    run = lambda: node_epoch(net, opt, X, X, y, tr, va)
+    if a.layout != 'single':
+        import torch.distributed as dist
+        from magnet_amd import dist as D
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1)
+        if a.layout == 'rows':
+            part = D.RowPartition.from_global(lap.row_ptr, lap.col_idx, lap.val, n, 0, 1, lambda rp, ci, v, nc: type(lap)(rp, ci, v, nc))
+            sh = D.RowShardedChebNet(net, part)
+        else:
+            sh = D.ShardedChebNet(net, lap, n, 0, 1)
+        sh.cache_input_propagation = a.cached
+        xp = torch.stack([X, X], dim=1).contiguous()
+        n_tr, n_va = int(tr.numel()), int(va.numel())
+        run = lambda: sh.epoch(opt, xp, y, tr, va, n_tr, n_va)
     for _ in range(2):
-        node_epoch(net, opt, X, X, y, tr, va)
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.epochs):
-        node_epoch(net, opt, X, X, y, tr, va)
+        run()
     torch.cuda.synchronize()
-    print('epoch %.2f ms (nnz %d, cached=%s)' % ((time.perf_counter() - t0) / a.epochs * 1e3, lap.nnz, a.cached))
+    print('epoch %.2f ms (nnz %d, cached=%s, layout=%s)' % ((time.perf_counter() - t0) / a.epochs * 1e3, lap.nnz, a.cached, a.layout))
 
 
 if __name__ == '__main__':
