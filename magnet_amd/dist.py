@@ -714,6 +714,39 @@ class _RegroupFn(torch.autograd.Function):
         return _regroup(g.contiguous(), rb, cb, rank, world, group, not to_cols), None, None, None, None, None, None
 
 
+class _OrdersGemmFn(torch.autograd.Function):
+    """Row-local tail of a conv: orders side by side z [R, 2, k1, C_in] -> sum_k z_k W_k + bias, complex ReLU fused
+    (one GEMM, the bias / ReLU kernel in place).  Backward: the ReLU mask applied in place of a copy, the weight
+    gradient as a split-K gram of two tall matrices (a single GEMM would have too few output tiles for 256 CUs), the
+    input gradient only when the orders need one."""
+
+    @staticmethod
+    def forward(ctx, z, w, b, relu):
+        from .layer import sparse_magnet as M
+        rows, _, k1, cin = z.shape
+        cout = w.size(2)
+        zf = z.reshape(rows * 2, k1 * cin)
+        out = torch.mm(zf, w.reshape(k1 * cin, cout)).view(rows, 2, cout)
+        mask = M._bias_relu_(out, b, relu)
+        ctx.save_for_backward(zf, w, mask)
+        ctx.has_bias, ctx.shape = b is not None, (rows, k1, cin, cout)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .layer import sparse_magnet as M
+        zf, w, mask = ctx.saved_tensors
+        rows, k1, cin, cout = ctx.shape
+        g = g.contiguous()
+        if mask is not None:
+            g = M._relu_bwd_(g.clone(), mask)
+        g2 = g.view(rows * 2, cout)
+        dz = torch.mm(g2, w.reshape(k1 * cin, cout).t()).view(rows, 2, k1, cin) if ctx.needs_input_grad[0] else None
+        dw = M._gram(zf, g2).view(k1, cin, cout) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0).view(1, cout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dz, dw, db, None
+
+
 class ShardedChebNet:
     """Runs a ChebNet (magnet_amd.layer.sparse_magnet.ChebNet, same parameters / state_dict) on
     `world` GPUs.  Every rank holds the whole Laplacian; node features enter as row blocks.  Layers
@@ -775,9 +808,7 @@ class ShardedChebNet:
                 c = (x_rows, x_rows._version, r, k1)
                 if self.cache_input_propagation:
                     self._input_cache = c
-            rf, wf = c[2].reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)
-            out = (torch.addmm(b.reshape(1, cout), rf, wf) if b is not None else torch.matmul(rf, wf)).view(rows_me, 2, cout)
-            x = _ComplexReluFn.apply(out) if relu0 else out
+            x = _OrdersGemmFn.apply(c[2], w, b, relu0)
             layers = layers[1:]
         for conv, relu in layers:
             w, b = conv.weight, conv.bias
@@ -792,10 +823,7 @@ class ShardedChebNet:
             else:
                 z = _ChebTermsFn.apply(x, self.op, k1)
                 r = self._regroup(z, cur_cb, False)
-                out = torch.matmul(r.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)).view(rows_me, 2, cout)
-                if b is not None:
-                    out = out + b.reshape(1, 1, cout)
-                x = _ComplexReluFn.apply(out) if relu else out
+                x = _OrdersGemmFn.apply(r, w, b, relu)
                 layout = 'rows'
         if layout == 'cols':
             x = self._regroup(x.unsqueeze(2), cur_cb, False).squeeze(2)
@@ -882,8 +910,6 @@ class RowShardedChebNet(ShardedChebNet):
                 z = c[2]
             else:
                 z = _RowTermsFn.apply(x, self.part, k1)                              # [rows_me, 2, k1, cin]
-            zf, wf = z.reshape(rows_me * 2, k1 * cin), w.reshape(k1 * cin, cout)
-            out = (torch.addmm(b.reshape(1, cout), zf, wf) if b is not None else torch.matmul(zf, wf)).view(rows_me, 2, cout)
-            x = _ComplexReluFn.apply(out) if relu else out
+            x = _OrdersGemmFn.apply(z, w, b, relu)
         return x
 
