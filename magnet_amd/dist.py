@@ -646,13 +646,15 @@ class ColumnSharded:
         if staged:
             handles.append(self.last_order_staged(zs[-1], zs[-2] if k1 > 2 else None))
         rows_me = self.r1 - self.r0
-        out = None
-        for k, h in enumerate(handles):
-            a = self.finish_regroup(h).reshape(rows_me * 2, cin)
-            if out is None:
-                out = torch.addmm(bias, a, weight[k]) if bias is not None else torch.mm(a, weight[k])
-            else:
-                out.addmm_(a, weight[k])
+        # the peers' column slices of every order land side by side in one block, which ONE GEMM with the stacked
+        # weights then reads (the copy out of the receive buffers is the one a concatenation would make)
+        block = torch.empty((rows_me, 2, k1, cin), dtype=x_slice.dtype, device=x_slice.device)
+        for k, (works, recv, _) in enumerate(handles):
+            wait_all(works)
+            for p in range(self.world):
+                block[:, :, k, self.cb[p]:self.cb[p + 1]].copy_(recv[p])
+        bf, wf = block.view(rows_me * 2, k1 * cin), weight.reshape(k1 * cin, cout)
+        out = torch.addmm(bias, bf, wf) if bias is not None else torch.mm(bf, wf)
         return out.view(rows_me, 2, cout)
 
 
