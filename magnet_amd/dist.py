@@ -30,6 +30,9 @@ Row partition
   while the exchange of Z_{k-1} is still in flight, waits for it, then adds  a L_ext Z_{k-1}.  That covers
   more than the interior-row split (rows without any remote column): every nonzero with a local column
   overlaps, whatever row it sits in.
+* L_ext's columns count from the start of the halo, so own rows and halo rows need not share a tensor: a conv keeps
+  its own rows of all K+1 orders side by side in one [n_local, 2, K+1, F] block (cheb_block), which one GEMM with the
+  stacked weights reads, and every order's halo in a contiguous [n_halo, 2, F] tensor of its own.
 * The weight GEMM and the bias act on rows independently, so the output block needs no exchange;
   a conv of K orders performs K exchanges (its input's halo and K-1 intermediate orders).  Weight
   gradients are all-reduced (tiny).
