@@ -196,38 +196,52 @@ __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_counts(const int32_t* 
 // A run longer than kLongRun records (the same directed pair listed hundreds of times) is not walked
 // by one thread: its head is put on a list and a whole wavefront sums it (segments_long).
 // ---------------------------------------------------------------------------
-__device__ inline uint8_t finish_segment(float fwd, float bwd, int64_t p, float* seg_s, float* seg_d) {
-    float s = 0.5f * (fwd + bwd);                  // hermitian.py:147
-    float d = fwd - bwd;                           // hermitian.py:157
-    seg_s[p] = s; seg_d[p] = d;
+__device__ inline void segment_values(float fwd, float bwd, float& s, float& d) {
+    s = 0.5f * (fwd + bwd);                        // hermitian.py:147
+    d = fwd - bwd;                                 // hermitian.py:157
+}
+__device__ inline uint8_t segment_kept(float s, float d) {
     return (d != 0.0f && s != 0.0f) ? 1 : 0;       // exact zeros are not stored by the CSR binops
 }
 
+// Walks the run of records that starts at p (key k) for at most kLongRun records, adding the weights side by side in
+// stored order.  Returns false when the run is longer than that (its sums then come from segments_long).
+__device__ inline bool walk_run(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted, int64_t m, int64_t p,
+                                uint64_t k, float& fwd, float& bwd) {
+    const uint64_t pair = k >> 1;
+    fwd = 0.0f; bwd = 0.0f;
+    int64_t t = p;
+    uint64_t kt = k;
+    for (int step = 0; step < kLongRun; ++step) {
+        float w = w_sorted ? w_sorted[t] : 1.0f;
+        if (kt & 1ull) bwd += w; else fwd += w;
+        ++t;
+        if (t >= m) return true;
+        kt = keys[t];
+        if ((kt >> 1) != pair) return true;
+    }
+    return false;
+}
+
+// Short runs leave only their keep flag here: the emission walks the (at most kLongRun) records again, from lines the
+// neighbouring threads have just brought into the caches, which is cheaper than writing s and delta for 400M records
+// and reading them back.  Long runs get their sums from segments_long, stored at the head's index in seg_s / seg_d.
 __global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
-                                                   int64_t m, float* __restrict__ seg_s, float* __restrict__ seg_d,
-                                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_list,
+                                                   int64_t m, uint8_t* __restrict__ flags, uint32_t* __restrict__ long_list,
                                                    Header* hdr) {
     int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= m) return;
     uint64_t k = keys[p];
-    uint64_t pair = k >> 1;
-    bool head = (p == 0) || ((keys[p - 1] >> 1) != pair);
+    bool head = (p == 0) || ((keys[p - 1] >> 1) != (k >> 1));
     uint8_t keep = 0;
     if (head) {
-        float fwd = 0.0f, bwd = 0.0f;
-        int64_t t = p;
-        uint64_t kt = k;
-        bool ended = false;
-        for (int step = 0; step < kLongRun; ++step) {
-            float w = w_sorted ? w_sorted[t] : 1.0f;
-            if (kt & 1ull) bwd += w; else fwd += w;
-            ++t;
-            if (t >= m) { ended = true; break; }
-            kt = keys[t];
-            if ((kt >> 1) != pair) { ended = true; break; }
+        float fwd, bwd, s, d;
+        if (walk_run(keys, w_sorted, m, p, k, fwd, bwd)) {
+            segment_values(fwd, bwd, s, d);
+            keep = segment_kept(s, d);
+        } else {
+            long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag written by segments_long
         }
-        if (ended) keep = finish_segment(fwd, bwd, p, seg_s, seg_d);
-        else long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag written by segments_long
     }
     flags[p] = keep;
 }
@@ -269,7 +283,12 @@ __global__ void __launch_bounds__(kBlock) segments_long(const uint64_t* __restri
             }
             if (cnt < 64) break;                                          // the run ended inside these 64 records
         }
-        if (lane == 0) flags[p] = finish_segment(fwd, bwd, p, seg_s, seg_d);
+        if (lane == 0) {
+            float sv, dv;
+            segment_values(fwd, bwd, sv, dv);
+            seg_s[p] = sv; seg_d[p] = dv;
+            flags[p] = segment_kept(sv, dv);
+        }
     }
 }
 
@@ -284,7 +303,8 @@ __global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restric
 // ---------------------------------------------------------------------------
 // 6. emission
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ flags,
+__global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
+                                                       const uint8_t* __restrict__ flags,
                                                        const uint32_t* __restrict__ pos, const float* __restrict__ seg_s,
                                                        const float* __restrict__ seg_d, const float* __restrict__ dinv,
                                                        int64_t m, int cb, int32_t row_lo, float two_pi_q, float scale, int diag,
@@ -303,8 +323,11 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
     const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
     if (tag < kTagCap) dc = inv_sqrt_degree(double(tag));     // the column's record count travelled in the key
     else dc = dinv[c];
-    float a = (dinv[r] * seg_s[p]) * dc;               // (D A_s) D, hermitian.py:154
-    float theta = two_pi_q * seg_d[p];                 // fp32 product, hermitian.py:157
+    float fwd, bwd, sv, dv;
+    if (walk_run(keys, w_sorted, m, p, k, fwd, bwd)) segment_values(fwd, bwd, sv, dv);
+    else { sv = seg_s[p]; dv = seg_d[p]; }             // a long run: summed by segments_long
+    float a = (dinv[r] * sv) * dc;                     // (D A_s) D, hermitian.py:154
+    float theta = two_pi_q * dv;                       // fp32 product, hermitian.py:157
     float sn, cs;
     sincosf(theta, &sn, &cs);                          // full-range accurate sincos, hermitian.py:158
     float re = -(cs * a), im = -(sn * a);              // I - Theta.*A_s off the diagonal, hermitian.py:164
@@ -425,7 +448,7 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int
     float* seg_s = reinterpret_cast<float*>(W.keys0);           // keys0 is free after the sort
     float* seg_d = seg_s + L.m_pad;
     if (L.m > 0) {
-        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.flags, W.long_list, W.hdr);
+        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, W.flags, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments");
         segments_long<<<1024, kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.flags, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments_long");
@@ -462,7 +485,7 @@ int fill_sorted(const Layout& L, const Work& W, bool tagged, int32_t row_lo, int
     if (L.m > 0 && nnz > 0) {
         MH_REQUIRE(col_idx && val, "col_idx/val is null");
         MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
-        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.flags, W.pos, seg_s, seg_d, dinv, L.m, L.cb, row_lo,
+        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, W.flags, W.pos, seg_s, seg_d, dinv, L.m, L.cb, row_lo,
                                                            two_pi_q, scale, diag, nnz, tagged ? 1 : 0, col_idx,
                                                            reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_entries");
