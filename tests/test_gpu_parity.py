@@ -140,7 +140,11 @@ def test_builder_full_size_properties():
     # q = 0.25 and integer weight differences: every phase is a multiple of pi/2
     ang = torch.atan2(-L.val[:, 1], -L.val[:, 0]) / (np.pi / 2)
     assert float((ang - ang.round()).abs().max()) < 1e-3
-    del A, rows, cols, key
+    # |L_rc| = d_r^-1/2 s d_c^-1/2 with s a multiple of 1/2 (unit weights): the column's d^-1/2, which this build takes
+    # from the record count carried in the key (from the table for the hubs), agrees with the returned degree vector
+    half_steps = mod / (L.dinv[rows] * L.dinv[cols]) * 2.0
+    assert float((half_steps - half_steps.round()).abs().max()) < 1e-4 and float(half_steps.min()) > 0.99
+    del A, rows, cols, key, half_steps
     # degrees: d^-1/2 came back
     assert L.dinv.numel() == n and float(L.dinv.max()) <= 2 ** 0.5 + 1e-6    # d >= 1/2 or d := 1
 
