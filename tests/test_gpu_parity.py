@@ -118,6 +118,42 @@ def test_generator_matches_oracle():
         assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(d.cpu().numpy(), do)
 
 
+def _check_sampled_rows(L, src, dst, n, q, n_samples, seed):
+    """Rows of a built Laplacian against the definition (hermitian.py:136-168, unit weights, lambda_max = 2) evaluated
+    in float64 straight from the edge list, for a random sample of rows plus the heaviest ones: structure exact,
+    values to 1e-5."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    src, dst = src.long(), dst.long()
+    deg2 = torch.bincount(src, minlength=n) + torch.bincount(dst, minlength=n)          # records per row = 2 * degree
+    d = 0.5 * deg2.double()
+    dinv = torch.where(d == 0, torch.ones_like(d), d) ** -0.5
+    rows = torch.unique(torch.cat([torch.randint(0, n, (n_samples,), device=DEV, generator=g), torch.topk(deg2, 3).indices]))
+    pick = torch.zeros(n, dtype=torch.bool, device=DEV); pick[rows] = True
+    f_sel, b_sel = pick[src], pick[dst]
+    key = torch.cat([src[f_sel] * n + dst[f_sel], dst[b_sel] * n + src[b_sel]])          # (row, col) of forward / backward records
+    is_b = torch.cat([torch.zeros(int(f_sel.sum()), device=DEV), torch.ones(int(b_sel.sum()), device=DEV)]).double()
+    uniq, inv = torch.unique(key, return_inverse=True)
+    nb = torch.zeros(uniq.numel(), dtype=torch.float64, device=DEV).index_add_(0, inv, is_b)
+    nf = torch.zeros(uniq.numel(), dtype=torch.float64, device=DEV).index_add_(0, inv, 1.0 - is_b)
+    s_, delta = 0.5 * (nf + nb), nf - nb
+    keep = delta != 0
+    uniq, s_, delta = uniq[keep], s_[keep], delta[keep]
+    r, c = uniq // n, uniq % n
+    a = dinv[r] * s_ * dinv[c]
+    theta = 2.0 * np.pi * q * delta
+    want = torch.stack([-(a * torch.cos(theta)), -(a * torch.sin(theta))], dim=1)
+    rp = L.row_ptr.long()
+    lens = (rp[rows + 1] - rp[rows])
+    got_rows = torch.repeat_interleave(rows, lens)
+    offs = torch.arange(int(lens.sum()), device=DEV) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+    at = torch.repeat_interleave(rp[rows], lens) + offs
+    got_key = got_rows * n + L.col_idx[at].long()
+    assert torch.equal(got_key, uniq), 'structure of the sampled rows'
+    err = float((L.val[at].double() - want).abs().max())
+    assert err <= 1e-5 * float(want.abs().max()), err
+    return int(rows.numel()), int(at.numel())
+
+
 def test_builder_full_size_properties():
     """Config-4 sized graph (2M nodes / 40M edges): properties that hold at any size."""
     _, lap, H, _, _ = _mods()
@@ -145,6 +181,8 @@ def test_builder_full_size_properties():
     half_steps = mod / (L.dinv[rows] * L.dinv[cols]) * 2.0
     assert float((half_steps - half_steps.round()).abs().max()) < 1e-4 and float(half_steps.min()) > 0.99
     del A, rows, cols, key, half_steps
+    n_rows, n_entries = _check_sampled_rows(L, src, dst, n, 0.25, 20000, 5)
+    assert n_rows > 19000 and n_entries > 500000
     # degrees: d^-1/2 came back
     assert L.dinv.numel() == n and float(L.dinv.max()) <= 2 ** 0.5 + 1e-6    # d >= 1/2 or d := 1
 
@@ -1008,6 +1046,9 @@ def test_spmm_full_size_properties():
     n, e, f = 10_000_000, 200_000_000, 256
     src, dst = lap.powerlaw_edges(n, e, 43, device=DEV)
     L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    # the builder at this size (24 node bits: record counts travel in the keys' 15 spare bits, the hubs overflow them)
+    # against the definition on 20 000 sampled rows and the heaviest three
+    _check_sampled_rows(L, src, dst, n, 0.25, 20000, 6)
     del src, dst
     assert L.nnz % 2 == 0 and 0 < L.nnz <= 2 * e
     plan, n_long, n_chunks, chunk = L.plan()
