@@ -1450,6 +1450,22 @@ def test_integration_stub_from_the_docs_runs():
     assert_close(cx(Y).real, want.real); assert_close(cx(Y).imag, want.imag)
 
 
+def test_relabelling_snippet_from_the_docs_runs():
+    """The multi-GPU relabelling recipe of INTEGRATION.md, executed as written with one rank."""
+    import re
+    _, lap, _, _, _ = _mods()
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if 'balanced_label_propagation' in b]
+    assert len(blocks) == 1
+    n = 3000
+    src, dst = lap.powerlaw_edges(n, 40000, 3, device=DEV)
+    ns = {'src': src.long(), 'dst': dst.long(), 'n': n, 'world': 1, 'rank': 0, 'q': 0.25, 'x': torch.randn(n, 4, device=DEV)}
+    exec(compile(blocks[0], 'INTEGRATION.md', 'exec'), ns)
+    assert ns['block'].n_rows == n and ns['x_mine'].shape == (n, 4) and ns['bounds'] == [0, n]
+    L = lap.build_magnetic_laplacian(ns['new_of_old'][src.long()], ns['new_of_old'][dst.long()], n, q=0.25)
+    assert torch.equal(L.col_idx, ns['block'].col_idx) and torch.equal(L.val, ns['block'].val)
+
+
 def test_backward_fused_and_lazy_clenshaw_agree():
     """dX = sum_k T_k (G W_k^T): the K+1 matrices G W_k^T come from one GEMM when they fit a memory budget
     and one at a time inside the recurrence otherwise (10M-node graphs); both forms give the same gradients."""
