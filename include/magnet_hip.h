@@ -161,6 +161,11 @@ int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, const float
  * that GPU's buffer: calls that overlap in time on one GPU (different streams or threads) race; calls
  * ordered on one stream do not.  Nothing of an earlier call is read: every chunk slot is written before
  * it is combined.
+ * FIRST CALL PER DEVICE: the address of that device's buffer is looked up once (hipGetSymbolAddress, under
+ * a mutex; the runtime may load the code object at that moment).  That lookup is not a stream operation and
+ * must not happen inside a HIP graph capture: make the first call on a device — or call
+ * mh_cspmm_noalloc_init() with that device current — before capturing.  Every later call on the device reads
+ * the cached address with one atomic load and takes no lock.
  */
 #define MH_NOALLOC_SCRATCH_BYTES (64u << 20)
 int mh_cspmm_planned_noalloc(const int32_t* row_ptr, const int32_t* col_idx, const float* val, int32_t n_rows,
@@ -172,6 +177,17 @@ int mh_cspmm_planned_noalloc(const int32_t* row_ptr, const int32_t* col_idx, con
                              const float* bias, int relu, uint8_t* mask_out, int32_t F,
                              const int32_t* plan, int32_t n_long, int32_t n_chunks, int32_t chunk,
                              void* stream);
+/* Resolves the built-in buffer's address on the CURRENT device (the set-up step of the entry point above; no
+ * counterpart in the reference).  Idempotent, synchronous, allocates nothing. */
+int mh_cspmm_noalloc_init(void);
+
+/* Launch-width knob (no counterpart in the reference).  Bounds the number of workgroups (256 threads = 4
+ * wavefronts, one row per wavefront at a time) that the row kernel of the following mh_cspmm* calls OF THE
+ * CALLING THREAD is launched with; 0 restores the default (enough workgroups to fill the GPU).  Results do
+ * not depend on it.  For callers that run a propagation order next to other GPU work - the row-partitioned
+ * multi-GPU propagation launches the own-column product with a reduced width so that the copy kernels of the
+ * halo exchange find free compute units. */
+int mh_cspmm_set_grid_cap(int32_t workgroups);
 
 /* Whole recursions in one call (the loop over orders of ChebConv.forward,
  * src/layer/sparse_magnet.py:60-68, with the polynomials of src/utils/hermitian.py:117-134
@@ -247,6 +263,10 @@ int mh_bias_relu(float* Y, int64_t ld, int64_t im, const float* bias, int relu,
  * src/layer/sparse_magnet.py:80-81; the mask itself carries no gradient). */
 int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask,
                 int64_t n_rows, int32_t F, void* stream);
+/* The same, out of place: out = G * mask with its own (ldo, imo); out may be G, or e.g. one order of a
+ * side-by-side block [N][2][K+1][F] that the backward recursion then continues from (no copy of G first). */
+int mh_relu_bwd_to(const float* G, int64_t ld, int64_t im, const uint8_t* mask,
+                   float* out, int64_t ldo, int64_t imo, int64_t n_rows, int32_t F, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Synthetic power-law digraph (bench / scale tests).  Edge e (0-based, global

@@ -85,6 +85,12 @@ def _load():
     lib.mh_bias_relu.argtypes = [vp, i64, i64, vp, C.c_int, vp, i64, i32, vp]
     lib.mh_relu_bwd.restype = C.c_int
     lib.mh_relu_bwd.argtypes = [vp, i64, i64, vp, i64, i32, vp]
+    lib.mh_relu_bwd_to.restype = C.c_int
+    lib.mh_relu_bwd_to.argtypes = [vp, i64, i64, vp, vp, i64, i64, i64, i32, vp]
+    lib.mh_cspmm_noalloc_init.restype = C.c_int
+    lib.mh_cspmm_noalloc_init.argtypes = []
+    lib.mh_cspmm_set_grid_cap.restype = C.c_int
+    lib.mh_cspmm_set_grid_cap.argtypes = [i32]
     lib.mh_powerlaw_edges.restype = C.c_int
     lib.mh_powerlaw_edges.argtypes = [i32, i64, u64, i64, vp, vp, vp]
     lib.mh_stream_read.restype = C.c_int
@@ -97,8 +103,8 @@ lib = _load()
 # operators the extension registers (csrc/torch_ext.cpp)
 OPS = ['cspmm', 'cspmm_noalloc', 'plan_build', 'cheb_terms_', 'clenshaw', 'lap_build', 'lap_block_count',
        'lap_block_fill', 'pack', 'unpack',
-       'gather_rows', 'scatter_rows', 'bias_relu_', 'relu_bwd_', 'halo_plan', 'powerlaw_edges', 'stream_read',
-       'version']
+       'gather_rows', 'scatter_rows', 'bias_relu_', 'relu_bwd_', 'relu_bwd_out', 'halo_plan', 'powerlaw_edges', 'stream_read',
+       'set_spmm_grid_cap', 'noalloc_init', 'version']
 
 
 def _guarded(op):
@@ -133,10 +139,10 @@ EXPORTS = [
     'mh_version', 'mh_last_error',
     'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
     'mh_lap_block_workspace_bytes', 'mh_lap_block_count', 'mh_lap_block_fill',
-    'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
+    'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_noalloc_init', 'mh_cspmm_set_grid_cap', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
     'mh_cheb_terms', 'mh_clenshaw',
     'mh_halo_plan_workspace_bytes', 'mh_halo_plan_count', 'mh_halo_plan_fill',
-    'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd',
+    'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd', 'mh_relu_bwd_to',
     'mh_powerlaw_edges', 'mh_stream_read',
 ]
 

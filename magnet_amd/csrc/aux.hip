@@ -22,7 +22,7 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace mh
 
-extern "C" int mh_version(void) { return 200; }
+extern "C" int mh_version(void) { return 300; }
 extern "C" const char* mh_last_error(void) { return mh::error_buffer(); }
 
 namespace {
@@ -97,45 +97,86 @@ __global__ void __launch_bounds__(kBlock) bias_relu_kernel(float* __restrict__ Y
     }
 }
 
-// row-planar -> two planar matrices
+// row-planar -> two planar matrices; one thread per float (or float4)
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock) unpack_kernel(const float* __restrict__ in, int64_t ld, int64_t im,
                                                         float* __restrict__ re, int64_t ld_re, float* __restrict__ im_,
                                                         int64_t ld_im, int64_t n_rows, int32_t F) {
-    const int64_t total = n_rows * 2 * F;
+    const int per_row = VEC ? (F >> 2) : F;
+    const int64_t total = n_rows * 2 * per_row;
     for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < total; t += int64_t(gridDim.x) * kBlock) {
-        int64_t r = t / (2 * F);
-        int rem = int(t - r * 2 * F);
-        int part = rem / F, c = rem - part * F;
-        float v = in[r * ld + (part ? im : 0) + c];
-        if (part) im_[r * ld_im + c] = v; else re[r * ld_re + c] = v;
+        int64_t r = t / (2 * per_row);
+        int rem = int(t - r * 2 * per_row);
+        int part = rem / per_row, c = rem - part * per_row;
+        const float* src = in + r * ld + (part ? im : 0);
+        float* dst = part ? im_ + r * ld_im : re + r * ld_re;
+        if (VEC) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+        else dst[c] = src[c];
     }
 }
 
-// rows idx[i] of a row-planar matrix <-> row i of a dense buffer [n_idx][2][F]; one wave per row
-template <bool GATHER>
+// rows idx[i] of a row-planar matrix <-> row i of a dense buffer [n_idx][2][F].  VEC: `lpr` lanes (a power of two,
+// at most 64) move one row as float4 items over both parts, 64 / lpr rows per wavefront; otherwise one wave per row,
+// one float per lane and step.
+template <bool GATHER, bool VEC>
 __global__ void __launch_bounds__(kBlock) move_rows_kernel(float* __restrict__ X, int64_t ld, int64_t im,
                                                            const int32_t* __restrict__ idx, int64_t n_idx,
-                                                           float* __restrict__ buf, int32_t F) {
+                                                           float* __restrict__ buf, int32_t F, int lpr) {
     const int lane = threadIdx.x & 63;
-    for (int64_t i = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6; i < n_idx; i += (int64_t(gridDim.x) * kBlock) >> 6) {
-        float* xr = X + int64_t(idx[i]) * ld;
-        float* b = buf + i * 2 * F;
-        for (int c = lane; c < F; c += 64) {
-            if (GATHER) { b[c] = xr[c]; b[F + c] = xr[im + c]; }
-            else { xr[c] = b[c]; xr[im + c] = b[F + c]; }
+    const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = (int64_t(gridDim.x) * kBlock) >> 6;
+    if (VEC) {
+        const int per_wave = 64 / lpr, sub = lane / lpr, l = lane & (lpr - 1);
+        const int nvec = F >> 2;
+        for (int64_t i = wave * per_wave + sub; i < n_idx; i += n_waves * per_wave) {
+            float* xr = X + int64_t(idx[i]) * ld;
+            float* b = buf + i * 2 * F;
+            for (int t = l; t < 2 * nvec; t += lpr) {
+                const int part = t >= nvec ? 1 : 0, c = t - part * nvec;
+                float4* px = reinterpret_cast<float4*>(xr + (part ? im : 0)) + c;
+                float4* pb = reinterpret_cast<float4*>(b + (part ? F : 0)) + c;
+                if (GATHER) *pb = *px; else *px = *pb;
+            }
+        }
+    } else {
+        for (int64_t i = wave; i < n_idx; i += n_waves) {
+            float* xr = X + int64_t(idx[i]) * ld;
+            float* b = buf + i * 2 * F;
+            for (int c = lane; c < F; c += 64) {
+                if (GATHER) { b[c] = xr[c]; b[F + c] = xr[im + c]; }
+                else { xr[c] = b[c]; xr[im + c] = b[F + c]; }
+            }
         }
     }
 }
 
-__global__ void __launch_bounds__(kBlock) relu_bwd_kernel(float* __restrict__ G, int64_t ld, int64_t im,
-                                                          const uint8_t* __restrict__ mask, int64_t n_rows, int32_t F) {
-    const int64_t total = n_rows * F;
+// out = G * mask on both parts (out may be G itself); one thread per feature (or four)
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) relu_bwd_kernel(const float* G, int64_t ld, int64_t im,
+                                                          const uint8_t* __restrict__ mask, float* out, int64_t ldo,
+                                                          int64_t imo, int64_t n_rows, int32_t F) {
+    const int per_row = VEC ? (F >> 2) : F;
+    const int64_t total = n_rows * per_row;
     for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < total; t += int64_t(gridDim.x) * kBlock) {
-        int64_t r = t / F;
-        int c = int(t - r * F);
-        float m = mask[t] ? 1.f : 0.f;
-        float* g = G + r * ld + c;
-        g[0] *= m; g[im] *= m;
+        int64_t r = t / per_row;
+        int c = int(t - r * per_row);
+        if (VEC) {
+            const uint32_t m = *reinterpret_cast<const uint32_t*>(mask + r * F + 4 * c);
+            const float mx = (m & 0xffu) ? 1.f : 0.f, my = (m & 0xff00u) ? 1.f : 0.f;
+            const float mz = (m & 0xff0000u) ? 1.f : 0.f, mw = (m & 0xff000000u) ? 1.f : 0.f;
+            const float* g = G + r * ld + 4 * c;
+            float4 gr = *reinterpret_cast<const float4*>(g), gi = *reinterpret_cast<const float4*>(g + im);
+            gr.x *= mx; gr.y *= my; gr.z *= mz; gr.w *= mw;
+            gi.x *= mx; gi.y *= my; gi.z *= mz; gi.w *= mw;
+            float* o = out + r * ldo + 4 * c;
+            *reinterpret_cast<float4*>(o) = gr; *reinterpret_cast<float4*>(o + imo) = gi;
+        } else {
+            float m = mask[r * F + c] ? 1.f : 0.f;
+            const float* g = G + r * ld + c;
+            float* o = out + r * ldo + c;
+            float gr = g[0] * m, gi = g[im] * m;
+            o[0] = gr; o[imo] = gi;
+        }
     }
 }
 
@@ -205,16 +246,24 @@ extern "C" int mh_bias_relu(float* Y, int64_t ld, int64_t im, const float* bias,
     return MH_OK;
 }
 
-extern "C" int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask, int64_t n_rows, int32_t F,
-                           void* stream_) {
+extern "C" int mh_relu_bwd_to(const float* G, int64_t ld, int64_t im, const uint8_t* mask, float* out, int64_t ldo,
+                              int64_t imo, int64_t n_rows, int32_t F, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MH_REQUIRE(n_rows >= 0 && F >= 1, "n_rows=%lld F=%d", (long long)n_rows, F);
     if (n_rows == 0) return MH_OK;
-    MH_REQUIRE(G && mask, "null pointer");
-    MH_REQUIRE(ld >= F && im >= F, "stride smaller than F");
-    relu_bwd_kernel<<<grid_for(n_rows * F, 1 << 20), kBlock, 0, stream>>>(G, ld, im, mask, n_rows, F);
+    MH_REQUIRE(G && mask && out, "null pointer");
+    MH_REQUIRE(ld >= F && im >= F && ldo >= F && imo >= F, "stride smaller than F");
+    const bool vec = mult4(F) && mult4(ld) && mult4(im) && mult4(ldo) && mult4(imo) && mh_aligned16(G) && mh_aligned16(out) &&
+                     (reinterpret_cast<uintptr_t>(mask) & 3u) == 0;
+    if (vec) relu_bwd_kernel<true><<<grid_for(n_rows * (F / 4), 1 << 20), kBlock, 0, stream>>>(G, ld, im, mask, out, ldo, imo, n_rows, F);
+    else relu_bwd_kernel<false><<<grid_for(n_rows * F, 1 << 20), kBlock, 0, stream>>>(G, ld, im, mask, out, ldo, imo, n_rows, F);
     MH_LAUNCH_CHECK("relu_bwd");
     return MH_OK;
+}
+
+extern "C" int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask, int64_t n_rows, int32_t F,
+                           void* stream_) {
+    return mh_relu_bwd_to(G, ld, im, mask, G, ld, im, n_rows, F, stream_);
 }
 
 extern "C" int mh_powerlaw_edges(int32_t n_nodes, int64_t n_edges, uint64_t seed, int64_t first_edge, int32_t* src,
@@ -265,10 +314,36 @@ extern "C" int mh_unpack(const float* in, int64_t ld, int64_t im, float* re, int
     if (n_rows == 0) return MH_OK;
     MH_REQUIRE(in && re && im_, "null pointer");
     MH_REQUIRE(ld_re >= F && ld_im >= F && ld >= F && im >= F, "stride smaller than F");
-    unpack_kernel<<<grid_for(n_rows * 2 * F, 1 << 20), kBlock, 0, stream>>>(in, ld, im, re, ld_re, im_, ld_im, n_rows, F);
+    const bool vec = mult4(F) && mult4(ld_re) && mult4(ld_im) && mult4(ld) && mult4(im) && mh_aligned16(in) &&
+                     mh_aligned16(re) && mh_aligned16(im_);
+    if (vec) unpack_kernel<true><<<grid_for(n_rows * 2 * (F / 4), 1 << 20), kBlock, 0, stream>>>(in, ld, im, re, ld_re, im_, ld_im, n_rows, F);
+    else unpack_kernel<false><<<grid_for(n_rows * 2 * F, 1 << 20), kBlock, 0, stream>>>(in, ld, im, re, ld_re, im_, ld_im, n_rows, F);
     MH_LAUNCH_CHECK("unpack");
     return MH_OK;
 }
+
+namespace {
+
+// lanes that move one row of 2 * F / 4 float4 items: the smallest power of two that covers them, at most 64
+inline int lanes_per_row(int32_t F) {
+    int lpr = 1;
+    while (lpr < 64 && lpr < 2 * (F >> 2)) lpr <<= 1;
+    return lpr;
+}
+
+template <bool GATHER>
+int move_rows(float* X, int64_t ld, int64_t im, const int32_t* idx, int64_t n_idx, float* buf, int32_t F, hipStream_t stream) {
+    const bool vec = mult4(F) && mult4(ld) && mult4(im) && mh_aligned16(X) && mh_aligned16(buf);
+    if (vec) {
+        const int lpr = lanes_per_row(F);
+        move_rows_kernel<GATHER, true><<<grid_for(n_idx * lpr, 1 << 16), kBlock, 0, stream>>>(X, ld, im, idx, n_idx, buf, F, lpr);
+    } else {
+        move_rows_kernel<GATHER, false><<<grid_for(n_idx * 64, 1 << 16), kBlock, 0, stream>>>(X, ld, im, idx, n_idx, buf, F, 64);
+    }
+    return MH_OK;
+}
+
+}  // namespace
 
 extern "C" int mh_gather_rows(const float* X, int64_t ld, int64_t im, const int32_t* idx, int64_t n_idx, float* buf,
                               int32_t F, void* stream_) {
@@ -277,7 +352,7 @@ extern "C" int mh_gather_rows(const float* X, int64_t ld, int64_t im, const int3
     if (n_idx == 0) return MH_OK;
     MH_REQUIRE(X && idx && buf, "null pointer");
     MH_REQUIRE(ld >= F && im >= F, "stride smaller than F");
-    move_rows_kernel<true><<<grid_for(n_idx * 64, 1 << 16), kBlock, 0, stream>>>(const_cast<float*>(X), ld, im, idx, n_idx, buf, F);
+    move_rows<true>(const_cast<float*>(X), ld, im, idx, n_idx, buf, F, stream);
     MH_LAUNCH_CHECK("gather_rows");
     return MH_OK;
 }
@@ -289,7 +364,7 @@ extern "C" int mh_scatter_rows(const float* buf, const int32_t* idx, int64_t n_i
     if (n_idx == 0) return MH_OK;
     MH_REQUIRE(X && idx && buf, "null pointer");
     MH_REQUIRE(ld >= F && im >= F, "stride smaller than F");
-    move_rows_kernel<false><<<grid_for(n_idx * 64, 1 << 16), kBlock, 0, stream>>>(X, ld, im, idx, n_idx, const_cast<float*>(buf), F);
+    move_rows<false>(X, ld, im, idx, n_idx, const_cast<float*>(buf), F, stream);
     MH_LAUNCH_CHECK("scatter_rows");
     return MH_OK;
 }

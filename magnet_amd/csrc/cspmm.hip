@@ -26,6 +26,7 @@
 //     the epilogue.
 // No float atomics, fixed summation order: results are bitwise reproducible.
 #include <cstdint>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -356,6 +357,10 @@ __global__ void __launch_bounds__(kBlock) plan_fill_kernel(const int32_t* __rest
     }
 }
 
+// Upper bound of workgroups of the row kernel for the calling thread's next launches (mh_cspmm_set_grid_cap);
+// 0 = the library default.
+thread_local int32_t t_grid_cap = 0;
+
 unsigned spmm_grid(int32_t n_rows) {
     int64_t want = (int64_t(n_rows) + kWavesPerBlock - 1) / kWavesPerBlock;
     static int64_t cap = -1;
@@ -364,6 +369,7 @@ unsigned spmm_grid(int32_t n_rows) {
         cap = e ? atoll(e) : int64_t(256) * 8 * 4;
     }
     if (want < 1) want = 1;
+    if (t_grid_cap > 0) return unsigned(want < t_grid_cap ? want : t_grid_cap);
     return unsigned((cap == 0 || want < cap) ? want : cap);
 }
 
@@ -487,26 +493,37 @@ extern "C" int mh_cspmm_planned(const int32_t* row_ptr, const int32_t* col_idx, 
 namespace {
 
 constexpr int kMaxDevices = 64;
-float* g_static_scratch[kMaxDevices];      // device address of `scratch` on each GPU, resolved on first use
+std::atomic<float*> g_static_scratch[kMaxDevices];      // device address of `scratch` on each GPU, resolved on first use
 std::mutex g_static_scratch_mu;
 
-// address of this GPU's copy of `scratch` (the current device's)
+// address of this GPU's copy of `scratch` (the current device's).  Once a device's address is known the call is one
+// atomic load; only the first call per device takes the mutex and asks the runtime.
 int static_scratch(float** out) {
     int dev = -1;
     MH_HIP(hipGetDevice(&dev));
     MH_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside [0, %d)", dev, kMaxDevices);
-    std::lock_guard<std::mutex> lock(g_static_scratch_mu);
-    if (!g_static_scratch[dev]) {
-        void* p = nullptr;
-        MH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        MH_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
-        g_static_scratch[dev] = static_cast<float*>(p);
+    float* p = g_static_scratch[dev].load(std::memory_order_acquire);
+    if (!p) {
+        std::lock_guard<std::mutex> lock(g_static_scratch_mu);
+        p = g_static_scratch[dev].load(std::memory_order_relaxed);
+        if (!p) {
+            void* sym = nullptr;
+            MH_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+            MH_REQUIRE(sym != nullptr, "hipGetSymbolAddress returned a null address");
+            p = static_cast<float*>(sym);
+            g_static_scratch[dev].store(p, std::memory_order_release);
+        }
     }
-    *out = g_static_scratch[dev];
+    *out = p;
     return MH_OK;
 }
 
 }  // namespace
+
+extern "C" int mh_cspmm_noalloc_init(void) {
+    float* p = nullptr;
+    return static_scratch(&p);
+}
 
 extern "C" int mh_cspmm_planned_noalloc(const int32_t* row_ptr, const int32_t* col_idx, const float* val,
                                         int32_t n_rows, const float* X, int64_t ldx, int64_t imx, float* Y,
@@ -540,6 +557,12 @@ extern "C" int mh_cspmm(const int32_t* row_ptr, const int32_t* col_idx, const fl
                         void* stream_) {
     return mh_cspmm_planned(row_ptr, col_idx, val, n_rows, X, ldx, imx, Y, ldy, imy, alpha, Z1, ldz1, imz1, beta1, Z2,
                             ldz2, imz2, beta2, bias, relu, mask_out, F, nullptr, 0, 0, 0, nullptr, 0, stream_);
+}
+
+extern "C" int mh_cspmm_set_grid_cap(int32_t workgroups) {
+    MH_REQUIRE(workgroups >= 0, "workgroups=%d", workgroups);
+    t_grid_cap = workgroups;
+    return MH_OK;
 }
 
 extern "C" size_t mh_cspmm_plan_ints(int32_t n_long, int32_t n_chunks) {

@@ -363,6 +363,27 @@ void relu_bwd_(Tensor& G, const Tensor& mask) {
     check_rc(mh_relu_bwd(g.p, g.ld, g.im, mask_of(mask, g.n, g.f), g.n, int32_t(g.f), stream_of(G)), "relu_bwd");
 }
 
+// out = G * mask (both parts); out may be a strided [N, 2, F] view, e.g. order 0 of a side-by-side block
+void relu_bwd_out(const Tensor& G, const Tensor& mask, Tensor& out) {
+    const c10::DeviceGuard guard(G.device());
+    Planar g = planar(G, "G"), o = planar(out, "out");
+    TORCH_CHECK(o.n == g.n && o.f == g.f, "out has shape ", out.sizes(), ", expected ", G.sizes());
+    check_rc(mh_relu_bwd_to(g.p, g.ld, g.im, mask_of(mask, g.n, g.f), o.p, o.ld, o.im, g.n, int32_t(g.f), stream_of(G)),
+             "relu_bwd_to");
+}
+
+// launch width of the calling thread's following cspmm calls (0 = default)
+void set_spmm_grid_cap(int64_t workgroups) {
+    TORCH_CHECK(workgroups >= 0 && workgroups <= INT32_MAX, "workgroups out of range");
+    check_rc(mh_cspmm_set_grid_cap(int32_t(workgroups)), "cspmm_set_grid_cap");
+}
+
+// set-up of cspmm_noalloc on a device (outside any graph capture)
+void noalloc_init(int64_t device_index) {
+    const c10::DeviceGuard guard(c10::Device(c10::DeviceType::CUDA, c10::DeviceIndex(device_index)));
+    check_rc(mh_cspmm_noalloc_init(), "cspmm_noalloc_init");
+}
+
 // ---- halo plan of a row block ------------------------------------------------------------------
 // (halo_ids [n_halo] ascending global column ids outside [c0, c1) that the block references,
 //  peer_ptr [world + 1]: halo_ids[peer_ptr[p] : peer_ptr[p+1]] lie in rows bounds[p] .. bounds[p+1] of peer p,
@@ -435,6 +456,9 @@ TORCH_LIBRARY(magnet, m) {
     m.def("scatter_rows(Tensor buf, Tensor idx, Tensor(a!) x) -> ()");
     m.def("bias_relu_(Tensor(a!) Y, Tensor? bias, bool relu, Tensor(b!)? mask) -> ()");
     m.def("relu_bwd_(Tensor(a!) G, Tensor mask) -> ()");
+    m.def("relu_bwd_out(Tensor G, Tensor mask, Tensor(a!) out) -> ()");
+    m.def("set_spmm_grid_cap(int workgroups) -> ()", &set_spmm_grid_cap);
+    m.def("noalloc_init(int device_index) -> ()", &noalloc_init);
     m.def("halo_plan(Tensor col_idx, int n_cols, int c0, int c1, Tensor bounds) -> (Tensor, Tensor, Tensor)");
     m.def("powerlaw_edges(int n_nodes, int seed, int first_edge, Tensor(a!) src, Tensor(b!) dst) -> ()");
     m.def("stream_read(Tensor buf, Tensor(a!) sink) -> ()");
@@ -456,6 +480,7 @@ TORCH_LIBRARY_IMPL(magnet, CUDA, m) {
     m.impl("scatter_rows", &scatter_rows);
     m.impl("bias_relu_", &bias_relu_);
     m.impl("relu_bwd_", &relu_bwd_);
+    m.impl("relu_bwd_out", &relu_bwd_out);
     m.impl("halo_plan", &halo_plan);
     m.impl("powerlaw_edges", &powerlaw_edges);
     m.impl("stream_read", &stream_read);

@@ -9,7 +9,7 @@ extension of its propagation (src/layer/sparse_magnet.py:50-72).  Two decomposit
   set-up scale with 1/world; the natural choice when a partition keeps most neighbours local.
 * ColumnSharded — every rank holds the whole Laplacian and a slice of the feature columns; the
   recursion needs no communication and one all-to-all per layer turns column slices into row
-  blocks for the weight GEMM.  (K-1)*world/(K+1) times fewer bytes on a graph without locality.
+  blocks for the weight GEMM.  K*world/(K+1) times fewer bytes on a graph without locality.
 
 Row partition
 -------------
@@ -23,8 +23,9 @@ Row partition
   sends every peer the rows that peer references (packed by a row-gather kernel; in place when the peer
   references the whole block) and receives its own halo rows straight into their slice of the buffer.
   The transfers are point-to-point sends/receives issued as one batch: on the fully connected xGMI mesh
-  every pair of GPUs has its own link, so all 7 peers are served concurrently (a ring would push 7x the
-  bytes through one link).
+  every pair of GPUs has its own link, so the batch is meant to serve all 7 peers concurrently (a ring would push
+  7x the bytes through one link).  Unmeasured on xGMI so far: the code has run on one GPU only (gloo staging and
+  one-rank RCCL groups); bench.py --gpus N records the variants of RowPartition.set_mode side by side.
 * To overlap the exchange with compute the block is split by COLUMN into L_int (own columns: operands
   already local) and L_ext (halo columns).  Order k runs  Z_k[own] = a L_int Z_{k-1} + b Z_{k-2}[own]
   while the exchange of Z_{k-1} is still in flight, waits for it, then adds  a L_ext Z_{k-1}.  That covers
@@ -107,6 +108,28 @@ def all_reduce(t, op=None, group=None):
     else:
         dist.all_reduce(t, op=op, group=group)
     return t
+
+
+class _StagedGather:
+    """all_gather_into_tensor of a device tensor carried by host copies (gloo moves host memory only)."""
+
+    def __init__(self, work, host_out, target):
+        self.work, self.host_out, self.target = work, host_out, target
+
+    def wait(self):
+        self.work.wait()
+        self.target.copy_(self.host_out)
+
+
+def start_all_gather(out, mine, group=None):
+    """ONE collective: every rank's `mine` (equal shapes, contiguous) lands in out[rank * len(mine) : ...] on all
+    ranks (RCCL all-gather over xGMI with the "nccl" backend; staged through host memory over gloo).  Returns a
+    handle with .wait()."""
+    if dist.get_backend(group) == 'gloo' and mine.is_cuda:
+        host_in = mine.cpu()
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        return _StagedGather(dist.all_gather_into_tensor(host_out, host_in, group=group, async_op=True), host_out, out)
+    return dist.all_gather_into_tensor(out, mine, group=group, async_op=True)
 
 
 def start_transfers(ops, group=None):
@@ -275,6 +298,49 @@ class RowPartition:
         # give[p]: the rows of this rank's block that peer p gathers = need[rank] of peer p
         self.give = exchange_lists(self.need, rank, world, group)
         self.comm_enabled = True          # False: skip the transfers (timing the compute alone)
+        self._make_operator, self._ext_csr = make_operator, (rpe, cie, ve)
+        self.mode = 'overlap'
+        self.int_grid_cap = 0             # workgroups of the own-column product in mode 'overlap_capped'
+        self.wait_events = None           # a list: (event before, event after) of every wait for an exchange
+        self.issue_seconds = None         # a list: host time spent issuing each exchange (packing launches + posting)
+        self._gathered = {}               # all_gather mode: feature width -> (staging block, gathered buffer)
+        self.L_ext_gathered = None
+
+    MODES = ('overlap', 'overlap_capped', 'sequential', 'all_gather')
+
+    def set_mode(self, mode, int_grid_cap=None):
+        """How an order's halo exchange and its two products are arranged:
+          'overlap'         the own-column product runs while the halo is in flight, the halo-column product after it
+          'overlap_capped'  the same with the own-column product launched on `int_grid_cap` workgroups only, so that
+                            the communication library's copy kernels find free compute units next to it
+          'sequential'      the exchange completes first, then both products (no overlap)
+          'all_gather'      the exchange is ONE all-gather of the ranks' own blocks (padded to the largest block) into a
+                            buffer of all rows, which the halo-column product reads through columns renumbered to that
+                            buffer; every row travels whether a peer references it or not, so it suits graphs without
+                            locality, where the halo is nearly everything anyway; overlapped like 'overlap'."""
+        if mode not in self.MODES:
+            raise ValueError('mode must be one of %s' % (self.MODES,))
+        self.mode = mode
+        if int_grid_cap is not None:
+            self.int_grid_cap = int(int_grid_cap)
+        if mode == 'all_gather' and self.L_ext_gathered is None and self.world > 1:
+            # halo slot -> global row id -> (owner, row inside the owner's block) -> owner * max_rows + row
+            b = torch.tensor(self.bounds, dtype=torch.int64, device=self.halo_ids.device)
+            self.max_rows = max(self.bounds[p + 1] - self.bounds[p] for p in range(self.world))
+            gid = self.halo_ids.long()
+            owner = torch.searchsorted(b, gid, right=True) - 1
+            slot_to_gathered = (owner * self.max_rows + (gid - b[owner])).to(torch.int32)
+            rpe, cie, ve = self._ext_csr
+            self.L_ext_gathered = self._make_operator(rpe, slot_to_gathered[(cie - self.n_local).long()], ve,
+                                                      self.world * self.max_rows)
+        return self
+
+    def _gather_buffers(self, f, device, dtype):
+        bufs = self._gathered.get(f)
+        if bufs is None:
+            stage = torch.zeros((self.max_rows, 2, f), dtype=dtype, device=device)
+            bufs = self._gathered[f] = (stage, torch.empty((self.world * self.max_rows, 2, f), dtype=dtype, device=device))
+        return bufs
 
     @classmethod
     def from_global(cls, row_ptr, col_idx, val, n, rank, world, make_operator, group=None, row_mover=None, bounds=None):
@@ -305,6 +371,20 @@ class RowPartition:
         where this rank's halo rows arrive."""
         if self.world == 1 or not self.comm_enabled:
             return None
+        if self.issue_seconds is not None:
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._start_exchange(own, halo)
+            finally:
+                self.issue_seconds.append(time.perf_counter() - t0)
+        return self._start_exchange(own, halo)
+
+    def _start_exchange(self, own, halo):
+        if self.mode == 'all_gather':
+            stage, gathered = self._gather_buffers(own.size(2), own.device, own.dtype)
+            stage[:self.n_local].copy_(own)
+            return ([start_all_gather(gathered, stage, self.group)], [stage])
         ops, staged = [], []
         nl, pp = self.n_local, self.peer_ptr
         for step in range(1, self.world):
@@ -320,8 +400,19 @@ class RowPartition:
         return (start_transfers(ops, self.group), staged)
 
     def finish_exchange(self, handle):
+        """Makes the stream wait for the exchange (RCCL: the compute stream waits for the communication stream; the
+        host does not block).  With `wait_events` set, HIP events on the compute stream bracket the wait: their
+        distance is how long the stream sat idle for the halo, i.e. what the overlap failed to hide."""
         if handle:
-            wait_all(handle[0])
+            ev = self.wait_events
+            if ev is not None and handle[0] and torch.cuda.is_available():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                wait_all(handle[0])
+                e1.record()
+                ev.append((e0, e1))
+            else:
+                wait_all(handle[0])
 
     def propagate(self, z_prev, z_out, alpha=1.0, z_prev2=None, beta=0.0, pending=None, add=None, add_beta=1.0):
         """z_out[own] = alpha * (L z_prev)[own] + beta * z_prev2[own] (+ add_beta * add, a matrix of the rank's own
@@ -334,11 +425,27 @@ class RowPartition:
     def propagate_split(self, prev_own, prev_halo, out_own, alpha=1.0, prev2_own=None, beta=0.0, pending=None, add=None,
                         add_beta=1.0):
         """propagate() on operands given as (own rows, halo rows) pairs; the own-row matrices may be strided views."""
-        self.L_int.spmm(prev_own, out=out_own, alpha=alpha, z1=prev2_own, beta1=beta,
-                        z2=add, beta2=add_beta if add is not None else 0.0)
+        mode = self.mode
+        if mode == 'sequential':
+            self.finish_exchange(pending)
+            pending = None
+        capped = mode == 'overlap_capped' and self.int_grid_cap > 0 and pending is not None
+        if capped:
+            from ._lib import ops
+            ops.set_spmm_grid_cap(self.int_grid_cap)
+        try:
+            self.L_int.spmm(prev_own, out=out_own, alpha=alpha, z1=prev2_own, beta1=beta,
+                            z2=add, beta2=add_beta if add is not None else 0.0)
+        finally:
+            if capped:
+                ops.set_spmm_grid_cap(0)
         self.finish_exchange(pending)
         if self.n_halo:
-            self.L_ext.spmm(prev_halo, out=out_own, alpha=alpha, z1=out_own, beta1=1.0)
+            if mode == 'all_gather' and self.world > 1 and self.comm_enabled:
+                gathered = self._gathered[prev_own.size(2)][1]
+                self.L_ext_gathered.spmm(gathered, out=out_own, alpha=alpha, z1=out_own, beta1=1.0)
+            else:
+                self.L_ext.spmm(prev_halo, out=out_own, alpha=alpha, z1=out_own, beta1=1.0)
         return out_own
 
     def cheb_block(self, block, halos=None, halo_valid=False):
@@ -348,6 +455,8 @@ class RowPartition:
         when not given): they arrive there straight from the peers, and only the halo-column part of the operator
         reads them.  `halo_valid`: halos[0] already holds x's halo."""
         n_terms, f = block.size(2), block.size(3)
+        if halo_valid and self.mode == 'all_gather':
+            raise ValueError("halo_valid is not available in mode 'all_gather' (the halo lives in the gathered buffer)")
         if halos is None:
             halos = [torch.empty((self.n_halo, 2, f), dtype=block.dtype, device=block.device) for _ in range(max(n_terms - 1, 0))]
         order = lambda k: block[:, :, k, :]
@@ -364,6 +473,8 @@ class RowPartition:
         """[T_0 x, ..., T_{n-1} x] as compact buffers whose own rows are valid (and, for all but the last
         order, the halo).  x_buf holds the rank's rows of x; its halo is fetched first unless `halo_valid`."""
         zs = [x_buf]
+        if halo_valid and self.mode == 'all_gather':
+            raise ValueError("halo_valid is not available in mode 'all_gather' (the halo lives in the gathered buffer)")
         pending = None if (halo_valid or n_terms < 2) else self.exchange(x_buf)
         for k in range(1, n_terms):
             z = buffers[k - 1] if buffers is not None else torch.empty_like(x_buf)
@@ -426,14 +537,15 @@ def bounds_from_degrees(deg, world, row_cost=2):
     return partition_bounds(rp, world, row_cost)
 
 
-def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None, max_eigen=2.0):
+def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None, max_eigen=2.0, timing=None):
     """This rank's row block of the magnetic Laplacian, built from the edges incident to its rows
     (mh_lap_block_*), plus the bounds of all ranks.  `edge_chunks()` returns an iterator over
     (row, col[, weight]) device tensors that together list every edge, in the same order on every rank
     (a replicated list or a seeded generator); it is called once for the degrees when `bounds` is not given and
     once for the records.  Ranks exchange only d^-1/2 (an all-reduce of n floats in which every node is
     non-zero on exactly one rank, so the sum is exact).  Returns (MagneticLaplacian block with global
-    column ids, bounds)."""
+    column ids, bounds).  `timing`: a dict that receives 'block_build_ms' (mh_lap_block_* + the d^-1/2 all-reduce,
+    HIP events) apart from the streaming, counting and selection of the edges around it."""
     from .laplacian import LaplacianBlockBuild
     dev = None
     if bounds is None:
@@ -449,11 +561,14 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
         del deg
     r0, r1 = bounds[rank], bounds[rank + 1]
     parts = [[], [], [], [], [], []]                 # fwd row, col, w ; bwd row, col, w
-    weighted = False
+    weighted = None
     for chunk in edge_chunks():
         row, col = chunk[0], chunk[1]
         w = chunk[2] if len(chunk) > 2 else None
-        weighted = weighted or w is not None
+        if weighted is None:
+            weighted = w is not None
+        elif weighted != (w is not None):
+            raise ValueError('edge_chunks() mixes chunks with and without weights')
         dev = row.device
         f = (row >= r0) & (row < r1)
         b = (col >= r0) & (col < r1)
@@ -461,17 +576,28 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
         parts[3].append(row[b]); parts[4].append(col[b])
         if w is not None:
             parts[2].append(w[f]); parts[5].append(w[b])
+    if weighted is None:
+        raise ValueError('edge_chunks() yielded nothing (it must be re-iterable: it is called once per pass)')
     cat = lambda xs: torch.cat(xs) if len(xs) > 1 else xs[0]
     fwd = (cat(parts[0]), cat(parts[1])) + ((cat(parts[2]),) if weighted else ())
     bwd = (cat(parts[3]), cat(parts[4])) + ((cat(parts[5]),) if weighted else ())
     del parts
+    timed = timing is not None and dev.type == 'cuda'
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     build = LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=max_eigen)
     del fwd, bwd
     dinv = torch.zeros(n, dtype=torch.float32, device=dev)
     dinv[r0:r1] = build.dinv_block
     if world > 1:
         all_reduce(dinv, group=group)
-    return build.finish(dinv, q), bounds
+    blk = build.finish(dinv, q)
+    if timed:
+        ev1.record()
+        ev1.synchronize()
+        timing['block_build_ms'] = ev0.elapsed_time(ev1)
+    return blk, bounds
 
 
 class RowPartitionedConv:
@@ -546,8 +672,9 @@ class ColumnSharded:
     before it every order is regrouped from column slices to row blocks with an all-to-all (each
     rank sends 1/world of what it holds to every peer); the all-to-all of order k is in flight while
     order k+1 is computed.  Per conv that moves
-    (K+1) * N * 8F * (world-1)/world^2 bytes per rank, against (K-1) * N * 8F * (world-1)/world
-    for the row partition on a graph without locality — (K-1) * world / (K+1) times less."""
+    (K+1) * N * 8F * (world-1)/world^2 bytes per rank, against K * N * 8F * (world-1)/world
+    for the row partition on a graph without locality (K exchanges per conv: row_partition_floats) —
+    K * world / (K+1) times less.  Volumes only: no transfer of either layout has been timed on xGMI yet."""
 
     def __init__(self, operator, n, n_features, rank, world, group=None):
         self.op, self.n, self.rank, self.world, self.group = operator, n, rank, world, group
@@ -742,9 +869,7 @@ class _OrdersGemmFn(torch.autograd.Function):
         from .layer import sparse_magnet as M
         zf, w, mask = ctx.saved_tensors
         rows, k1, cin, cout = ctx.shape
-        g = g.contiguous()
-        if mask is not None:
-            g = M._relu_bwd_(g.clone(), mask)
+        g = M._relu_bwd(g, mask) if mask is not None else g.contiguous()
         g2 = g.view(rows * 2, cout)
         dz = torch.mm(g2, w.reshape(k1 * cin, cout).t()).view(rows, 2, k1, cin) if ctx.needs_input_grad[0] else None
         dw = M._gram(zf, g2).view(k1, cin, cout) if ctx.needs_input_grad[1] else None
@@ -853,12 +978,19 @@ class ShardedChebNet:
 
     def epoch(self, opt, x_rows, label_rows, train_rows, val_rows, n_train, n_val):
         """One epoch of the reference loop (src/sparse_Magnet.py:143-176) on this rank's rows:
-        label_rows [1, rows_me], train_rows / val_rows index tensors into the local rows,
-        n_train / n_val the GLOBAL numbers of training / validation nodes."""
+        label_rows [1, rows_me], train_rows / val_rows index tensors into the local rows (or train.NodeTargets made
+        from them: no gather of the predictions), n_train / n_val the GLOBAL numbers of training / validation nodes."""
         import torch.nn.functional as F
+        from .train import NodeTargets
+
+        def nll_sum(preds, idx):
+            # NodeTargets of the local rows: the sum over the rank's subset without gathering the predictions
+            if isinstance(idx, NodeTargets):
+                return idx.loss(preds, reduction='sum')
+            return F.nll_loss(preds[:, :, idx], label_rows[:, idx], reduction='sum')
         self.net.train()
         preds = self.forward(x_rows)
-        loss = F.nll_loss(preds[:, :, train_rows], label_rows[:, train_rows], reduction='sum') / n_train
+        loss = nll_sum(preds, train_rows) / n_train
         opt.zero_grad()
         loss.backward()
         self.all_reduce_grads()
@@ -866,7 +998,7 @@ class ShardedChebNet:
         self.net.eval()
         with torch.no_grad():
             preds = self.forward(x_rows)
-            vloss = F.nll_loss(preds[:, :, val_rows], label_rows[:, val_rows], reduction='sum') / n_val
+            vloss = nll_sum(preds, val_rows) / n_val
         stats = torch.stack([loss.detach(), vloss])
         if self.world > 1:
             all_reduce(stats, group=self.group)

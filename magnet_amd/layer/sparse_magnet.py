@@ -154,6 +154,20 @@ def _relu_bwd_(g, mask):
     return g
 
 
+def _relu_bwd(g, mask, out=None):
+    """out = g * mask on both parts (backward of the complex ReLU), out of place: `g` is read where it lies
+    (any row-planar strides), `out` is a new contiguous tensor or the given [N, 2, F] view — e.g. order 0 of a
+    side-by-side block — so the incoming gradient is neither made contiguous nor cloned first."""
+    n, _, f = g.shape
+    if (f > 1 and g.stride(2) != 1) or (n > 1 and g.stride(0) < f) or g.stride(1) < f:
+        g = g.contiguous()
+    if out is None:
+        out = torch.empty((n, 2, f), dtype=torch.float32, device=g.device)
+    if n:
+        ops.relu_bwd_out(g, mask, out)
+    return out
+
+
 # ----------------------------------------------------------------------------
 # Chebyshev propagation with the fused SpMM
 # ----------------------------------------------------------------------------
@@ -283,9 +297,10 @@ class _ChebConvFn(torch.autograd.Function):
             # T_k G side by side; G (times the ReLU mask) goes straight into order 0
             ds = _new_block(n, k1, cout, g.device)
             g0 = _order(ds, 0)
-            g0.copy_(g)
             if ctx.relu:
-                _relu_bwd_(g0, ctx.mask)
+                _relu_bwd(g, ctx.mask, out=g0)
+            else:
+                g0.copy_(g)
             if need_b:
                 db = g0.sum(dim=(0, 1)).view(1, cout)     # the same real bias sits on both parts
             if need_w or need_x:
@@ -295,9 +310,7 @@ class _ChebConvFn(torch.autograd.Function):
             if need_x:
                 dx = torch.mm(_block_rows(ds), w.transpose(1, 2).reshape(k1 * cout, cin)).view(n, 2, cin)
         else:
-            g = g.contiguous()
-            if ctx.relu:
-                g = _relu_bwd_(g.clone(), ctx.mask)
+            g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
             if need_b:
                 db = g.sum(dim=(0, 1)).view(1, cout)
             g2 = _rows2(g)
@@ -345,9 +358,7 @@ class _ClenshawFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        if ctx.relu:
-            g = _relu_bwd_(g.clone(), ctx.mask)
+        g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
         db = g.sum(dim=(0, 1)) if ctx.has_bias and ctx.needs_input_grad[1] else None
         dy = _cheb_terms(ctx.lap, g, ctx.k1) if ctx.needs_input_grad[0] else None
         return dy, db, None, None
@@ -380,9 +391,7 @@ class _ListConvFn(torch.autograd.Function):
         k1, _, cout = weight.shape
         nl = len(ctx.laps)
         w = weight.detach()
-        g = g.contiguous()
-        if ctx.relu:
-            g = _relu_bwd_(g.clone(), ctx.mask)
+        g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
         dx = dw = db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g.sum(dim=(0, 1)).view(1, cout)
@@ -407,7 +416,7 @@ class _ComplexReluFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _relu_bwd_(g.contiguous().clone(), ctx.mask)
+        return _relu_bwd(g, ctx.mask)
 
 
 # ----------------------------------------------------------------------------

@@ -10,25 +10,56 @@ import torch
 import torch.nn.functional as F
 
 
+IGNORE = -100          # F.nll_loss's default ignore_index
+
+
+class NodeTargets:
+    """The labels of a node subset in the form the loss reads without gathering: `label` [1, N] with every node
+    outside the subset set to IGNORE, and the subset's size as a device scalar.  `index` is a boolean [N] mask or
+    an int64 index tensor, as node_epoch takes them.
+
+    The reference computes criterion(preds[:, :, index], label[:, index]) (src/sparse_Magnet.py:155): a gather of
+    the predictions, and in backward an index-put (with a sort of the indices) into a zero tensor.  The mean of
+    the negative log-likelihood over the subset is the same number as nll_loss over ALL nodes with the other
+    nodes ignored — no gather, no index-put, no sort; made once per split, reused every epoch."""
+
+    def __init__(self, label, index):
+        lab = torch.full_like(label, IGNORE)
+        lab[:, index] = label[:, index]
+        self.label = lab
+        self.count = (lab != IGNORE).sum()
+
+    def loss(self, preds, reduction='mean'):
+        return F.nll_loss(preds, self.label, ignore_index=IGNORE, reduction=reduction)
+
+    def accuracy(self, preds):
+        return (preds.max(dim=1)[1] == self.label).sum().float() / self.count
+
+
+def _loss_acc(preds, label, index, criterion):
+    if isinstance(index, NodeTargets):
+        return index.loss(preds), index.accuracy(preds)
+    loss = criterion(preds[:, :, index], label[:, index])
+    acc = (preds.max(dim=1)[1][:, index] == label[:, index]).float().mean()
+    return loss, acc
+
+
 def node_epoch(model, opt, X_real, X_img, label, train_index, val_index, criterion=None):
-    """label: [1, N] class ids; train_index / val_index: boolean [N] masks as in the reference, or
-    int64 index tensors (required under GraphedEpoch: boolean indexing synchronises).
+    """label: [1, N] class ids; train_index / val_index: boolean [N] masks as in the reference, int64 index
+    tensors (required under GraphedEpoch: boolean indexing synchronises), or NodeTargets made from either
+    (same loss and accuracy without the per-epoch gather and scatter; `criterion` is then NLL).
     Returns (train_loss, train_acc, val_loss, val_acc) as device scalars (no host sync)."""
     criterion = criterion or torch.nn.NLLLoss()
     model.train()
     preds = model(X_real, X_img)
-    train_loss = criterion(preds[:, :, train_index], label[:, train_index])
-    pred_label = preds.max(dim=1)[1]
-    train_acc = (pred_label[:, train_index] == label[:, train_index]).float().mean()
+    train_loss, train_acc = _loss_acc(preds, label, train_index, criterion)
     opt.zero_grad()
     train_loss.backward()
     opt.step()
     model.eval()
     with torch.no_grad():
         preds = model(X_real, X_img)
-        pred_label = preds.max(dim=1)[1]
-        val_loss = criterion(preds[:, :, val_index], label[:, val_index])
-        val_acc = (pred_label[:, val_index] == label[:, val_index]).float().mean()
+        val_loss, val_acc = _loss_acc(preds, label, val_index, criterion)
     return train_loss.detach(), train_acc, val_loss, val_acc
 
 

@@ -91,6 +91,61 @@ def _worker(rank, world, port, n_terms, out_dir, banded=False):
         dist.destroy_process_group()
 
 
+def _worker_modes(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        L, rp, ci, val = _graph()
+        n, f, n_terms = L.shape[0], 4, 4
+        part = D.RowPartition.from_global(rp, ci, val, n, rank, world, ScipyOperator)
+        x = torch.randn(n, 2, f, generator=torch.Generator().manual_seed(0))
+        ys = torch.randn(n, 2, n_terms, f, generator=torch.Generator().manual_seed(1))
+        out = {'bounds': part.bounds}
+        for mode in D.RowPartition.MODES:
+            part.set_mode(mode, int_grid_cap=64)
+            block = torch.full((part.n_local, 2, n_terms, f), float('nan'))
+            block[:, :, 0, :] = x[part.r0:part.r1]
+            part.cheb_block(block)
+            cl = part.clenshaw([ys[part.r0:part.r1, :, k, :] for k in range(n_terms)])
+            out[mode] = (block.clone(), cl.clone())
+        torch.save(out, os.path.join(out_dir, 'm%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_partition_exchange_modes_agree(world, tmp_path):
+    """Every arrangement of the halo exchange (overlapped point-to-point, the same with a capped launch width,
+    exchange-then-compute, one all-gather of the padded own blocks) gives the recursion and the Clenshaw sum of
+    the single-process run."""
+    mp.spawn(_worker_modes, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    L, rp, ci, val = _graph()
+    n, f, n_terms = L.shape[0], 4, 4
+    x = torch.randn(n, 2, f, generator=torch.Generator().manual_seed(0))
+    ys = torch.randn(n, 2, n_terms, f, generator=torch.Generator().manual_seed(1))
+    c = lambda t: t[:, 0, :].double().numpy() + 1j * t[:, 1, :].double().numpy()
+    Ld = L.astype(np.complex128)
+    ref = [c(x), Ld @ c(x)]
+    for k in range(2, n_terms):
+        ref.append(2 * (Ld @ ref[k - 1]) - ref[k - 2])
+    # sum_k T_k y_k with T_k applied by the same recursion
+    want_cl = np.zeros((n, f), dtype=np.complex128)
+    for k in range(n_terms):
+        t = [c(ys[:, :, k, :]), Ld @ c(ys[:, :, k, :])]
+        for j in range(2, k + 1):
+            t.append(2 * (Ld @ t[j - 1]) - t[j - 2])
+        want_cl += t[k]
+    outs = [torch.load(os.path.join(str(tmp_path), 'm%d.pt' % r)) for r in range(world)]
+    for mode in D.RowPartition.MODES:
+        for k in range(n_terms):
+            got = np.concatenate([c(o[mode][0][:, :, k, :]) for o in outs])
+            assert np.abs(got - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max(), (mode, k)
+        got = np.concatenate([c(o[mode][1]) for o in outs])
+        assert np.abs(got - want_cl).max() <= 1e-5 * np.abs(want_cl).max(), mode
+
+
 def _worker_cols(rank, world, port, n_terms, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -152,6 +207,10 @@ def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False):
             return m.to(torch.uint8)
         M._bias_relu_ = bias_relu_
         M._relu_bwd_ = lambda g, mask: g.mul_(mask.unsqueeze(1).float())
+        def relu_bwd(g, mask, out=None):
+            r = g * mask.unsqueeze(1).float()
+            return r if out is None else out.copy_(r)
+        M._relu_bwd = relu_bwd
         L, rp, ci, val = _graph()
         n, cin, Fh, K, ncls = L.shape[0], 6, 8, 2, 4
         op = ScipyOperator(rp, ci, val, n)

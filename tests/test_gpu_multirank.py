@@ -179,15 +179,15 @@ def test_row_partitioned_training_on_ranks_sharing_one_gpu(tmp_path):
 def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     """bench.py launched as the driver launches it for --gpus 2 (torch.distributed.run, one process per rank), both
     ranks on this GPU over gloo: the whole multi-rank control flow (per-rank build, strategy record, timed steps,
-    compute-only steps, secondary measurements) ends with one JSON line on rank 0."""
+    compute-only steps, the row-partition variants, the epoch in both layouts, the CPU baseline on rank 0) ends with
+    one JSON line on rank 0 that carries every field the first run on several GPUs is meant to decide from."""
     env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--nodes', '200000',
-           '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy, '--no-cpu-baseline']
-    # the column-sharded run also takes the secondary measurements: the same conv row-partitioned, and a training epoch
-    # of the sharded ChebNet (on a small graph here)
-    cmd += ['--epoch-nodes', '50000', '--epoch-edges', '1000000', '--epoch-layout', strategy]
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=110)
+           '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy,
+           '--cpu-sample-nodes', '20000', '--cpu-sample-edges', '200000']
+    cmd += ['--epoch-nodes', '50000', '--epoch-edges', '1000000']
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, res.stdout[-500:]
@@ -195,10 +195,30 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == strategy + '2' and d['value'] > 0
     m = d['multi_gpu']
     assert m['ranks_initialised'] == 2 and m['strategy'] == strategy and m['backend'] == 'gloo'
-    assert m['row_layout']['largest_halo_rows'] > 0 and m['row_layout']['bytes_sent_per_rank_per_order'] > 0
+    rl = m['row_layout']
+    assert rl['largest_halo_rows'] > 0 and rl['bytes_sent_per_rank_per_order'] > 0
+    assert 0 < rl['per_rank_block_build_ms'] < rl['edge_stream_and_block_build_ms']
     assert m['compute_only_ms_per_step'] > 0 and np.isfinite(m['exposed_comm_ms_per_step'])
-    assert 0 < m['row_layout']['largest_block_nnz'] < d['config']['nnz']
-    if strategy == 'cols':
-        assert d['row_partition']['ms_per_step'] > 0 and np.isfinite(d['row_partition']['exposed_comm_ms_per_step'])
-    assert d['epoch']['ms'] > 0 and d['epoch']['n_gpus'] == 2 and d['epoch']['ms_with_cached_input_propagation'] > 0
-    assert ('RowShardedChebNet' in d['epoch']['config']) == (strategy == 'rows')
+    assert 0 < rl['largest_block_nnz'] < d['config']['nnz']
+    # the whole-graph builder figures exist only where a whole-graph build ran
+    assert (d['builder_edges_per_s'] is None) == (strategy == 'rows')
+    # every arrangement of the row partition's exchange, with the per-order wait of the compute stream
+    v = m['row_variants']
+    for mode in ('overlap', 'overlap_capped', 'sequential', 'all_gather'):
+        assert v[mode]['ms_per_step'] > 0 and v[mode]['edges_per_s'] > 0, mode
+        assert len(v[mode]['exposed_wait_ms_per_order']) == 3 and all(w >= 0 for w in v[mode]['exposed_wait_ms_per_order']), mode
+        assert v[mode]['host_issue_ms_per_exchange_rank0'] > 0
+    assert v['overlap_capped']['own_column_product_workgroups'] > 0 and v['compute_only_ms_per_step'] > 0
+    assert v['all_gather']['rows_received_per_rank_per_order'] >= rl['largest_halo_rows']
+    assert d['row_partition']['ms_per_step'] == v['overlap']['ms_per_step']
+    # the epoch in both layouts, the row one over blocks the ranks built for themselves
+    ep = d['epoch']
+    assert ep['ms'] > 0 and ep['n_gpus'] == 2 and set(ep['layouts']) == {'rows', 'cols'}
+    for lay in ('rows', 'cols'):
+        e = ep['layouts'][lay]
+        assert e['ms'] > 0 and e['ms_with_cached_input_propagation'] > 0 and e['layout'] == lay, e
+    assert 'RowShardedChebNet' in ep['layouts']['rows']['config'] and ep['layouts']['rows']['block_build_ms_rank0'] > 0
+    assert ep['layouts']['rows']['nnz'] == ep['layouts']['cols']['nnz']
+    assert ep['ms'] == min(ep['layouts'][l]['ms'] for l in ep['layouts'])
+    # the CPU baseline is reported at every N
+    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['kind'] == 'port'
