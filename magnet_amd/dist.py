@@ -966,8 +966,8 @@ class ShardedChebNet:
         x = p.reshape(p.size(0), -1)
         if self.net.dropout > 0:
             x = F.dropout(x, self.net.dropout, training=self.net.training)
-        x = F.linear(x, self.net.Conv.weight.squeeze(-1), self.net.Conv.bias)
-        return F.log_softmax(x.t().unsqueeze(0), dim=1)
+        from .layer.sparse_magnet import _HeadFn
+        return F.log_softmax(_HeadFn.apply(x, self.net.Conv.weight.squeeze(-1), self.net.Conv.bias), dim=1)
 
     def all_reduce_grads(self):
         for p in self.net.parameters():

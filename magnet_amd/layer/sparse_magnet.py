@@ -53,6 +53,20 @@ class _PackFn(torch.autograd.Function):
         return g[:, 0, :], g[:, 1, :]
 
 
+class _PackIntoBlockFn(torch.autograd.Function):
+    """(real, imag) packed straight into order 0 of a new side-by-side block [N, 2, k1, F]; returns that order-0
+    view.  The conv that follows fills the other orders in place (no packed copy of the input in between)."""
+
+    @staticmethod
+    def forward(ctx, real, imag, k1):
+        block = _new_block(real.size(0), k1, real.size(1), real.device)
+        return pack_complex(real, imag, out=_order(block, 0))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, 0, :], g[:, 1, :], None
+
+
 def _as_packed(real, imag):
     """Row-planar tensor of a (real, imag) pair; free when the pair are views handed out by a layer here."""
     p = getattr(real, '_mh_packed', None)
@@ -265,11 +279,14 @@ class _ChebConvFn(torch.autograd.Function):
             else:
                 block = in_block if orders_ready else _fill_orders(lap, in_block)
             o2 = _rows2(out)
-            if b is None:
+            if b is None or relu:
+                # with an activation to apply the bias joins its in-place pass: addmm would first broadcast the bias into
+                # the output (one more write of it) and have the GEMM read that back
                 torch.mm(_block_rows(block), w.reshape(k1 * cin, cout), out=o2)
-            else:                                          # the bias rides on the GEMM's epilogue
+                mask = _bias_relu_(out, b, relu)
+            else:                                          # no activation pass: the bias rides on the GEMM
                 torch.addmm(b.reshape(1, cout), _block_rows(block), w.reshape(k1 * cin, cout), out=o2)
-            mask = _bias_relu_(out, None, relu)
+                mask = None
         ctx.x0 = None
         if (block is not None and not orders_ready and RECOMPUTE_ORDERS_BYTES > 0
                 and 8 * n * k1 * cin > RECOMPUTE_ORDERS_BYTES and ctx.needs_input_grad[1]):
@@ -405,6 +422,31 @@ class _ListConvFn(torch.autograd.Function):
                 h = torch.mm(g2, w[k].t()).view(g.size(0), 2, cin)
                 dx = lap.adjoint().spmm(h, z1=dx, beta1=1.0 if dx is not None else 0.0)
         return dx, dw, db, None, None
+
+
+class _HeadFn(torch.autograd.Function):
+    """Node-classification head: x [N, D] -> logits [1, C, N] = (x W^T + b)^T for a few classes (W [C, D]) — the
+    reference's Conv1d(2F, label_dim, kernel_size=1) on the [1, 2F, N] features (src/layer/sparse_magnet.py:113-117,
+    126-128), written class-major as log_softmax(dim=1) and the loss read it (no transposed copy).  Backward: the
+    weight gradient g x is a product of two tall matrices with a tiny result, taken as the split-K gram the convs use
+    (the library GEMM for a 5 x 256 result over 2M rows ran at a sixth of the rate the read of x allows); the bias
+    gradient is a row sum of the class-major gradient (a column sum of an [N, C] matrix keeps 8 workgroups busy)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        out = torch.mm(weight, x.t()) if bias is None else torch.addmm(bias.view(-1, 1), weight, x.t())
+        return out.unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.squeeze(0).contiguous()                                  # [C, N]
+        dx = torch.mm(g.t(), weight) if ctx.needs_input_grad[0] else None
+        dw = _gram(g.t(), x) if ctx.needs_input_grad[1] else None
+        db = g.sum(1) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
 
 
 class _ComplexReluFn(torch.autograd.Function):
@@ -597,6 +639,12 @@ class ChebConv(nn.Module):
                   and not imag.requires_grad and getattr(real, '_mh_packed', None) is None
                   and not (0 < RECOMPUTE_ORDERS_BYTES < 8 * real.size(0) * self._n_terms * real.size(1)))
         if not usable:
+            if (self._mode == 'cheb' and self._spmm_first() and self._n_terms > 1 and real.is_cuda and real.dim() == 2
+                    and real.shape == imag.shape and getattr(real, '_mh_packed', None) is None
+                    and not (0 < RECOMPUTE_ORDERS_BYTES < 8 * real.size(0) * self._n_terms * real.size(1))):
+                # the input goes straight into order 0 of the block this conv propagates in
+                xp = _PackIntoBlockFn.apply(real, imag, self._n_terms)
+                return self.forward_packed(xp, relu, next_terms, in_block=_block_of(xp, self._n_terms))
             return self.forward_packed(_as_packed(real, imag), relu, next_terms)
         c = getattr(self, '_input_cache', None)
         w = self.weight[:self._n_terms]
@@ -702,8 +750,7 @@ class ChebNet(nn.Module):
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
         # Conv1d with kernel 1 over [1, 2F, N] is a linear map per node
-        x = F.linear(x, self.Conv.weight.squeeze(-1), self.Conv.bias)
-        x = x.t().unsqueeze(0)
+        x = _HeadFn.apply(x, self.Conv.weight.squeeze(-1), self.Conv.bias)          # [1, label_dim, N]
         return F.log_softmax(x, dim=1)
 
 

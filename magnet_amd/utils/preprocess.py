@@ -66,7 +66,18 @@ def load_laplacian_cache(path, K=None, device='cuda'):
     executed) and return the ChebBasis of its T_1."""
     import scipy.sparse as sp
     L = read_sparse_list(path)
-    t1 = L[1]
-    n = t1['_shape'][0]
-    m = sp.csr_matrix((t1['data'], t1['indices'], t1['indptr']), shape=(n, n))
-    return ChebBasis(MagneticLaplacian.from_scipy(m, device=device), len(L) - 1 if K is None else K)
+    if len(L) == 0:
+        raise ValueError('%s holds an empty Laplacian list' % path)
+    order = len(L) - 1 if K is None else K
+    if len(L) == 1:
+        # a K = 0 cache holds T_0 = I alone: the Laplacian cannot be read back from it, and a network of that
+        # order never applies it.  An all-zero operator of the right size stands in (T_0 X = X needs no operator).
+        if order > 0:
+            raise ValueError('%s was written for K = 0 and holds T_0 only; order %d needs T_1' % (path, order))
+        n = L[0]['_shape'][0]
+        m = sp.csr_matrix((n, n), dtype=np.complex64)
+    else:
+        t1 = L[1]
+        n = t1['_shape'][0]
+        m = sp.csr_matrix((t1['data'], t1['indices'], t1['indptr']), shape=(n, n))
+    return ChebBasis(MagneticLaplacian.from_scipy(m, device=device), order)

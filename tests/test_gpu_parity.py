@@ -869,6 +869,16 @@ def test_in_out_degree_and_cache_glue(tmp_path):
     assert np.array_equal(T2.indices, G.indices) and np.abs(T2.data - G.data).max() <= 1e-5 * np.abs(G.data).max()
     e2 = P.to_edge_dataset_sparse(0.1, d.edge_index, 2, 0, n, root=root)
     assert len(e2) == 3 and e2.laplacian.nnz == 14680
+    # a K = 0 cache holds T_0 alone: it reads back as an order-0 basis (nothing to propagate), and cannot serve K > 0
+    _, _, _, _, _, b0 = P.geometric_dataset_sparse(0.05, 0, root=root, subset='', dataset=lambda root: [d])
+    zero = P.load_laplacian_cache(root + '/data0.05_0_sparse.pk')
+    assert len(b0) == 1 and len(zero) == 1 and zero.laplacian.n_rows == n and zero.laplacian.nnz == 0
+    conv = M.ChebConv(1, 4, 0, zero, None).to(DEV)
+    xr = torch.randn(n, 1, device=DEV)
+    r, i = conv((xr, xr))
+    assert_close(r.detach().cpu().numpy(), (xr @ conv.weight[0] + conv.bias).detach().cpu().numpy())
+    with pytest.raises(ValueError):
+        P.load_laplacian_cache(root + '/data0.05_0_sparse.pk', K=2)
 
 
 def test_column_sharded_conv_single_rank_on_gpu():
@@ -1079,6 +1089,29 @@ def test_spmm_full_size_properties():
         scale = max(float(re.abs().max()), float(im.abs().max()), 1e-3)
         worst = max(worst, float((Y[r, 0, :].double() - re).abs().max()) / scale,
                     float((Y[r, 1, :].double() - im).abs().max()) / scale)
+    assert worst <= 1e-5, worst
+    # The recursion as a conv runs it: the orders side by side in one [N, 2, K+1, F] block (61 GB here), every
+    # operand a strided view of it, order 2 with the axpy addend (alpha = 2, z1 = order 0, beta1 = -1).  Order 1 must
+    # be the product above; 2000 rows of order 2 against 2 (L z_1)[r] - x[r] in fp64 from the CSR and the GPU's order 1.
+    from magnet_amd.layer import sparse_magnet as M
+    del Y
+    block = torch.empty(n, 2, 3, f, device=DEV)
+    block[:, :, 0, :].copy_(X)
+    M._fill_orders(L, block)
+    z1 = L.spmm(X)
+    assert torch.equal(block[:, :, 1, :], z1)
+    del z1
+    worst = 0.0
+    for r in rows.tolist():
+        a, b = int(rp[r]), int(rp[r + 1])
+        cols = L.col_idx[a:b].long()
+        v = L.val[a:b].double()
+        zr = block[cols, 0, 1, :].double(); zi = block[cols, 1, 1, :].double()
+        re = 2.0 * (v[:, 0:1] * zr - v[:, 1:2] * zi).sum(0) - X[r, 0, :].double()
+        im = 2.0 * (v[:, 0:1] * zi + v[:, 1:2] * zr).sum(0) - X[r, 1, :].double()
+        scale = max(float(re.abs().max()), float(im.abs().max()), 1e-3)
+        worst = max(worst, float((block[r, 0, 2, :].double() - re).abs().max()) / scale,
+                    float((block[r, 1, 2, :].double() - im).abs().max()) / scale)
     assert worst <= 1e-5, worst
 
 
@@ -1516,3 +1549,140 @@ def test_recomputed_orders_give_the_same_gradients():
         M.RECOMPUTE_ORDERS_BYTES, M.ChebConv.cache_input_propagation = saved, saved_cache
     for a, b in zip(res['kept'], res['recomputed']):
         assert torch.equal(a, b)
+
+
+def test_training_step_gradients_at_full_size():
+    """Config-4 size (2M nodes / 40M edges, 128 -> 128 features, K = 2, complex ReLU): one ChebConv training step.
+    dW and db against float64 products of the propagated orders with the gated gradient, on the device; 2000 rows of
+    dX against the last step of Clenshaw's recurrence (dX = Y_0 + L b_1 - Y_2, Y_k = G W_k^T, b_1 = Y_1 + 2 L Y_2)
+    evaluated in float64 from the CSR (reference src/layer/sparse_magnet.py:8-18,60-72 under autograd)."""
+    _, lap, H, M, O = _mods()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip('needs ~45 GB of free HBM')
+    n, e, f, K = 2_000_000, 40_000_000, 128, 2
+    src, dst = lap.powerlaw_edges(n, e, 42, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    del src, dst
+    torch.manual_seed(5)
+    conv = M.ChebConv(f, f, K, H.cheb_poly_sparse(L, K), None).to(DEV)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.2, 0.2)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(n, 2, f, device=DEV, generator=g).requires_grad_(True)
+    wt = torch.randn(n, 2, f, device=DEV, generator=g)
+    out = conv.forward_packed(x, relu=True)
+    (out * wt).sum().backward()
+    with torch.no_grad():
+        pre = conv.forward_packed(x.detach(), relu=False)
+        gate = (pre[:, 0, :] >= 0)
+        assert torch.equal(out.detach(), pre * gate.unsqueeze(1))
+        G = wt * gate.unsqueeze(1)
+        del pre, out
+        # db = sum over nodes and parts
+        db = G.double().sum(dim=(0, 1))
+        assert float((conv.bias.grad.double().view(-1) - db).abs().max()) <= 1e-5 * float(db.abs().max()) + 8 * 6e-8 * float(G.abs().sum(dim=(0, 1)).max())
+        # dW_k = (T_k X)^T G over both parts, in float64 from the GPU's own orders (checked against fp64 elsewhere)
+        block = M._cheb_terms(L, x.detach(), K + 1)
+        G2 = G.view(2 * n, f).double()
+        for k in range(K + 1):
+            zk = block[:, :, k, :].reshape(2 * n, f).double()
+            want = zk.t() @ G2
+            got = conv.weight.grad[k].double()
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), 'dW[%d]' % k
+            del zk, want
+        del block, G2
+        # dX by Clenshaw: the GPU's b_1, then sampled rows of the last step in float64
+        W = conv.weight.detach()
+        g2 = G.view(2 * n, f)
+        Y = [torch.mm(g2, W[k].t()).view(n, 2, f) for k in range(K + 1)]
+        b1 = L.spmm(Y[2], alpha=2.0, z1=Y[1], beta1=1.0)
+        rows = torch.cat([torch.arange(0, 8, device=DEV), torch.randint(0, n, (2000,), device=DEV, generator=g)])
+        rp = L.row_ptr.long()
+        worst = 0.0
+        for r in rows.tolist():
+            a, b = int(rp[r]), int(rp[r + 1])
+            cols = L.col_idx[a:b].long()
+            v = L.val[a:b].double()
+            br, bi = b1[cols, 0, :].double(), b1[cols, 1, :].double()
+            re = Y[0][r, 0, :].double() + (v[:, 0:1] * br - v[:, 1:2] * bi).sum(0) - Y[2][r, 0, :].double()
+            im = Y[0][r, 1, :].double() + (v[:, 0:1] * bi + v[:, 1:2] * br).sum(0) - Y[2][r, 1, :].double()
+            scale = max(float(re.abs().max()), float(im.abs().max()), 1e-3)
+            worst = max(worst, float((x.grad[r, 0, :].double() - re).abs().max()) / scale,
+                        float((x.grad[r, 1, :].double() - im).abs().max()) / scale)
+        assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize('f', [1, 3, 4, 8, 20, 32, 64, 128, 256, 260, 1028])
+def test_layout_and_activation_helpers(f):
+    """mh_relu_bwd_to (out of place, strided source and destination), mh_unpack and the row staging kernels on their
+    float4 and scalar paths, against torch."""
+    _, lap, _, M, _ = _mods()
+    n = 1531
+    g = torch.Generator(device=DEV).manual_seed(f)
+    x = torch.randn(n, 2, f, device=DEV, generator=g)
+    mask = (torch.rand(n, f, device=DEV, generator=g) < 0.5).to(torch.uint8)
+    want = x * mask.bool().unsqueeze(1)
+    assert torch.equal(M._relu_bwd(x, mask), want)
+    blk = torch.full((n, 2, 3, f), 7.0, device=DEV)
+    assert torch.equal(M._relu_bwd(x, mask, out=blk[:, :, 1, :]), want)                      # into one order of a block
+    assert bool((blk[:, :, 0, :] == 7.0).all()) and bool((blk[:, :, 2, :] == 7.0).all())
+    assert torch.equal(M._relu_bwd(blk[:, :, 1, :], mask), want * mask.bool().unsqueeze(1))  # from a strided source
+    assert torch.equal(M._relu_bwd(x.expand(n, 2, f).permute(1, 0, 2).contiguous().permute(1, 0, 2), mask), want)
+    assert torch.equal(M._relu_bwd_(x.clone(), mask), want)
+    src = blk[:, :, 1, :]
+    re, im = lap.unpack_complex(src)
+    assert torch.equal(re, src[:, 0, :]) and torch.equal(im, src[:, 1, :])
+    idx = torch.randperm(n, device=DEV, generator=g)[:700].to(torch.int32)
+    buf = lap.gather_rows(src, idx)
+    assert torch.equal(buf, src[idx.long()])
+    tgt = torch.zeros(n, 2, 2, f, device=DEV)
+    lap.scatter_rows(buf, idx, tgt[:, :, 1, :])
+    assert torch.equal(tgt[idx.long(), :, 1, :], buf) and float(tgt[:, :, 0, :].abs().max()) == 0.0
+    assert int((tgt[:, :, 1, :].abs().sum((1, 2)) > 0).sum()) <= 700
+
+
+def test_launch_width_knob_leaves_results_unchanged():
+    """mh_cspmm_set_grid_cap bounds the row kernel's workgroups for the calling thread (the row partition launches the
+    own-column product narrow so that the exchange's copy kernels find free compute units): bitwise the same result,
+    and the default comes back with 0."""
+    mh, lap, _, _, _ = _mods()
+    n, e = 60_000, 1_500_000
+    src, dst = lap.powerlaw_edges(n, e, 7, device=DEV)
+    L = lap.build_magnetic_laplacian(src, dst, n, q=0.25)
+    x = torch.randn(n, 2, 64, device=DEV)
+    ref = L.spmm(x)
+    for cap in (1, 7, 512):
+        mh._lib.ops.set_spmm_grid_cap(cap)
+        try:
+            got = L.spmm(x)
+        finally:
+            mh._lib.ops.set_spmm_grid_cap(0)
+        assert torch.equal(got, ref), cap
+    with pytest.raises(mh.MagnetHipError):
+        mh._lib.ops.set_spmm_grid_cap(-1)
+
+
+def test_node_targets_give_the_reference_loss_without_gathering():
+    """train.NodeTargets (labels with the other nodes ignored) against the reference's
+    criterion(preds[:, :, index], label[:, index]) (src/sparse_Magnet.py:155): same loss, accuracy and gradients."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd.train import node_epoch, NodeTargets
+    row, col, n, _ = _telegram(0.25, False)
+    L = H.hermitian_decomp_sparse_device(row, col, n, 0.25)
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(n, 5, generator=g).to(DEV); y = torch.randint(0, 4, (1, n), generator=g).to(DEV)
+    train = (torch.rand(n, generator=g) < 0.6).to(DEV)
+    res = []
+    for form in ('mask', 'index', 'targets'):
+        torch.manual_seed(0)
+        net = M.ChebNet(5, H.cheb_poly_sparse(L, 2), None, num_filter=8, K=2, label_dim=4, activation=True, layer=2).to(DEV)
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        tr, va = {'mask': (train, ~train), 'index': (train.nonzero().squeeze(1), (~train).nonzero().squeeze(1)),
+                  'targets': (NodeTargets(y, train), NodeTargets(y, (~train).nonzero().squeeze(1)))}[form]
+        stats = [float(t) for t in node_epoch(net, opt, X, X, y, tr, va)]
+        res.append((stats, [p.grad.clone() for p in net.parameters()]))
+    for stats, grads in res[1:]:
+        assert_close(np.array(stats), np.array(res[0][0]), rel=1e-6, what='loss / accuracy')
+        for a, b in zip(grads, res[0][1]):
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9

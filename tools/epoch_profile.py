@@ -12,13 +12,14 @@ def main():
     p.add_argument('--edges', type=int, default=40_000_000)
     p.add_argument('--epochs', type=int, default=5)
     p.add_argument('--cached', action='store_true')
+    p.add_argument('--gather-loss', action='store_true', help='the reference form of the loss: criterion(preds[:, :, idx], label[:, idx])')
     p.add_argument('--layout', choices=['single', 'cols', 'rows'], default='single',
                    help='cols / rows: the multi-GPU networks (ShardedChebNet / RowShardedChebNet) with one rank')
     a = p.parse_args()
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges
     from magnet_amd.layer.sparse_magnet import ChebNet, ChebConv
     from magnet_amd.utils.hermitian import ChebBasis
-    from magnet_amd.train import node_epoch
+    from magnet_amd.train import node_epoch, NodeTargets
     dev = torch.device('cuda', 0)
     f, K, ncls, n = 128, 2, 5, a.nodes
     src, dst = powerlaw_edges(n, a.edges, 42, device=dev)
@@ -32,6 +33,9 @@ def main():
     y = torch.randint(0, ncls, (1, n), device=dev, generator=gen)
     train = torch.rand(n, device=dev, generator=gen) < 0.6
     tr = train.nonzero().squeeze(1); va = (~train).nonzero().squeeze(1)
+    n_tr, n_va = int(tr.numel()), int(va.numel())
+    if not a.gather_loss:
+        tr, va = NodeTargets(y, tr), NodeTargets(y, va)
     ChebConv.cache_input_propagation = a.cached
     run = lambda: node_epoch(net, opt, X, X, y, tr, va)
     if a.layout != 'single':
@@ -45,7 +49,6 @@ def main():
             sh = D.ShardedChebNet(net, lap, n, 0, 1)
         sh.cache_input_propagation = a.cached
         xp = torch.stack([X, X], dim=1).contiguous()
-        n_tr, n_va = int(tr.numel()), int(va.numel())
         run = lambda: sh.epoch(opt, xp, y, tr, va, n_tr, n_va)
     for _ in range(2):
         run()
