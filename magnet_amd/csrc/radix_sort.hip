@@ -93,21 +93,111 @@ __global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist,
     }
 }
 
-template <bool PAIRS, bool TAG>
-__global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
-                                                    const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
-                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag) {
-    __shared__ uint32_t cnt[kWaves][kBins];
-    __shared__ uint32_t digit_start[kBins];
-    __shared__ uint32_t goff[kBins];
-    __shared__ uint64_t skeys[kTile];
-    __shared__ float svals[PAIRS ? kTile : 1];
+// digit of a key given as its two halves; HI: the digit lies in the upper half (shift >= 32)
+template <bool HI>
+__device__ inline uint32_t digit_of2(uint32_t lo, uint32_t hi, int shift, uint32_t mask) {
+    const uint32_t v = HI ? hi >> (shift - 32) : __builtin_amdgcn_alignbit(hi, lo, uint32_t(shift));
+    return v & mask;
+}
 
+// (plo, phi) &= the lanes of the wavefront whose digit `d` equals this lane's in its low NB bits (NB = 7 or 8).
+// Per bit b: t = all ones when the lane's bit is set (v_bfe_i32), the ballot of that bit (v_cmp into a scalar register
+// pair), and per 32-bit half p &= ~(ballot ^ t) as one three-input bit operation (table 0x90 over (p, ballot, t)):
+// 4 vector instructions per bit.  Written out by hand: left to the compiler the same source took 9 per bit plus wait
+// states after every compare.  A compare's scalar result is read no sooner than three instructions later (two wait
+// states are required between a vector compare and a vector read of its scalar result).
+template <int NB>
+__device__ inline void match_lanes(uint32_t d, uint32_t& plo, uint32_t& phi) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    if (NB == 8) {
+        asm volatile(
+            "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+            "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+            "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
+            "v_bfe_i32 %[t3], %[d], 3, 1\n\t"
+            "v_cmp_ne_u32_e64 s[80:81], 0, %[t0]\n\t"
+            "v_cmp_ne_u32_e64 s[82:83], 0, %[t1]\n\t"
+            "v_cmp_ne_u32_e64 s[84:85], 0, %[t2]\n\t"
+            "v_cmp_ne_u32_e64 s[86:87], 0, %[t3]\n\t"
+            "v_bfe_i32 %[t4], %[d], 4, 1\n\t"
+            "v_bfe_i32 %[t5], %[d], 5, 1\n\t"
+            "v_bfe_i32 %[t6], %[d], 6, 1\n\t"
+            "v_bfe_i32 %[t7], %[d], 7, 1\n\t"
+            "v_cmp_ne_u32_e64 s[88:89], 0, %[t4]\n\t"
+            "v_cmp_ne_u32_e64 s[90:91], 0, %[t5]\n\t"
+            "v_cmp_ne_u32_e64 s[92:93], 0, %[t6]\n\t"
+            "v_cmp_ne_u32_e64 s[94:95], 0, %[t7]\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s80, %[t0] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s81, %[t0] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s82, %[t1] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s83, %[t1] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s84, %[t2] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s85, %[t2] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s86, %[t3] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s87, %[t3] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s88, %[t4] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s89, %[t4] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s90, %[t5] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s91, %[t5] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s92, %[t6] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s93, %[t6] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s94, %[t7] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s95, %[t7] bitop3:0x90\n\t"
+            : [plo] "+v"(plo), [phi] "+v"(phi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+              [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+            : [d] "v"(d)
+            : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+    } else {
+        asm volatile(
+            "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+            "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+            "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
+            "v_bfe_i32 %[t3], %[d], 3, 1\n\t"
+            "v_cmp_ne_u32_e64 s[80:81], 0, %[t0]\n\t"
+            "v_cmp_ne_u32_e64 s[82:83], 0, %[t1]\n\t"
+            "v_cmp_ne_u32_e64 s[84:85], 0, %[t2]\n\t"
+            "v_cmp_ne_u32_e64 s[86:87], 0, %[t3]\n\t"
+            "v_bfe_i32 %[t4], %[d], 4, 1\n\t"
+            "v_bfe_i32 %[t5], %[d], 5, 1\n\t"
+            "v_bfe_i32 %[t6], %[d], 6, 1\n\t"
+            "v_cmp_ne_u32_e64 s[88:89], 0, %[t4]\n\t"
+            "v_cmp_ne_u32_e64 s[90:91], 0, %[t5]\n\t"
+            "v_cmp_ne_u32_e64 s[92:93], 0, %[t6]\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s80, %[t0] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s81, %[t0] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s82, %[t1] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s83, %[t1] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s84, %[t2] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s85, %[t2] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s86, %[t3] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s87, %[t3] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s88, %[t4] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s89, %[t4] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s90, %[t5] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s91, %[t5] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[plo], %[plo], s92, %[t6] bitop3:0x90\n\t"
+            "v_bitop3_b32 %[phi], %[phi], s93, %[t6] bitop3:0x90\n\t"
+            : [plo] "+v"(plo), [phi] "+v"(phi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+              [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6)
+            : [d] "v"(d)
+            : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93");
+    }
+}
+
+struct ScatterShared {
+    uint32_t cnt[kWaves][kBins];
+    uint32_t digit_start[kBins];
+    uint32_t gdelta[kBins];          // global offset of a digit's run minus its start inside the tile
+    uint64_t skeys[kTile];
+};
+
+// One tile of a pass.  FULL: no key of the tile is out of range (every tile but the last).  NB: digit bits that are
+// matched (8, or 7 for the 7-bit digits of 42-bit keys).  HI: see digit_of2.
+template <bool PAIRS, bool TAG, int NB, bool HI, bool FULL>
+__device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint64_t* __restrict__ kin,
+                                    uint64_t* __restrict__ kout, const float* __restrict__ vin, float* __restrict__ vout,
+                                    int64_t n, int shift, uint32_t mask, uint32_t my_goff, const Tag& tag) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < kWaves * kBins; i += kThreads) (&cnt[0][0])[i] = 0;
-    if (tid < kBins) goff[tid] = offs[int64_t(blockIdx.x) * kBins + tid];
-    __syncthreads();
-
     const int64_t tile_base = int64_t(blockIdx.x) * kTile;
     const int64_t chunk_base = tile_base + int64_t(w) * (64 * kItems);
     uint64_t key[kItems];
@@ -116,7 +206,7 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         int64_t idx = chunk_base + i * 64 + lane;
-        bool ok = idx < n;
+        bool ok = FULL || idx < n;
         key[i] = ok ? kin[idx] : ~0ull;
         if (PAIRS) val[i] = ok ? vin[idx] : 0.f;
         if (TAG && ok) {
@@ -126,25 +216,27 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
             key[i] |= uint64_t(cnt < tag.cap ? cnt : tag.cap) << tag.tag_shift;
         }
     }
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // Ranking.  Per round the 64 keys of a wavefront are matched by digit with one ballot per digit bit: a lane keeps,
+    // in two 32-bit halves, the lanes that agree with it on every bit so far (match_lanes); the lanes of that set below
+    // it are its rank inside the round (mbcnt), the set's size advances the wave's running count of the digit.
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        const bool ok = chunk_base + i * 64 + lane < n;
-        const uint32_t d = digit_of(key[i], shift, mask);
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+        const uint32_t d = digit_of2<HI>(uint32_t(key[i]), uint32_t(key[i] >> 32), shift, mask);
+        uint32_t plo = ~0u, phi = ~0u;
+        bool ok = true;
+        if (!FULL) {
+            ok = chunk_base + i * 64 + lane < n;
+            const uint64_t live = __ballot(ok);
+            plo = uint32_t(live); phi = uint32_t(live >> 32);
         }
-        const uint32_t r = __popcll(peers & lt);
+        match_lanes<NB>(d, plo, phi);
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         // cnt[w][*] is private to this wavefront: every lane of a digit group reads the running count, then the
         // group's lowest lane advances it for the next round.  The wave barriers keep the compiler from moving
         // the LDS store across the other lanes' loads (the lanes of a wave execute in lockstep).
-        const uint32_t base = cnt[w][d];
+        const uint32_t base = sh.cnt[w][d];
         __builtin_amdgcn_wave_barrier();
-        if (ok && r == 0) cnt[w][d] = base + uint32_t(__popcll(peers));   // lowest lane of the group
+        if (ok && r == 0) sh.cnt[w][d] = base + uint32_t(__popc(plo) + __popc(phi));   // lowest lane of the group
         __builtin_amdgcn_wave_barrier();
         rank[i] = base + r;
     }
@@ -152,40 +244,77 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
     if (tid < kBins) {                     // per digit: offsets of the waves against each other, tile count
         uint32_t run = 0;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) { uint32_t t = cnt[ww][tid]; cnt[ww][tid] = run; run += t; }
-        digit_start[tid] = run;
+        for (int ww = 0; ww < kWaves; ++ww) { uint32_t t = sh.cnt[ww][tid]; sh.cnt[ww][tid] = run; run += t; }
+        sh.digit_start[tid] = run;
     }
     __syncthreads();
     {                                      // exclusive scan of the 256 tile counts
         uint32_t v = 0, inc = 0;
-        if (tid < kBins) { v = digit_start[tid]; inc = v; }
+        if (tid < kBins) { v = sh.digit_start[tid]; inc = v; }
         for (int off = 1; off < kBins; off <<= 1) {
-            uint32_t t = (tid < kBins && tid >= off) ? digit_start[tid - off] : 0u;
+            uint32_t t = (tid < kBins && tid >= off) ? sh.digit_start[tid - off] : 0u;
             __syncthreads();
-            if (tid < kBins) { inc = digit_start[tid] + t; digit_start[tid] = inc; }
+            if (tid < kBins) { inc = sh.digit_start[tid] + t; sh.digit_start[tid] = inc; }
             __syncthreads();
         }
-        if (tid < kBins) digit_start[tid] = inc - v;
+        if (tid < kBins) {
+            const uint32_t start = inc - v;
+            sh.gdelta[tid] = my_goff - start;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) sh.cnt[ww][tid] += start;     // slot of (wave, digit) inside the tile
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        if (chunk_base + i * 64 + lane < n) {
-            const uint32_t d = digit_of(key[i], shift, mask);
-            const uint32_t pos = digit_start[d] + cnt[w][d] + rank[i];
-            skeys[pos] = key[i];
+        if (FULL || chunk_base + i * 64 + lane < n) {
+            const uint32_t d = digit_of2<HI>(uint32_t(key[i]), uint32_t(key[i] >> 32), shift, mask);
+            const uint32_t pos = sh.cnt[w][d] + rank[i];
+            sh.skeys[pos] = key[i];
             if (PAIRS) svals[pos] = val[i];
         }
     }
     __syncthreads();
     const int64_t left = n - tile_base;
-    const int n_valid = left < kTile ? int(left) : kTile;
+    const int n_valid = FULL ? kTile : int(left);
     for (int j = tid; j < n_valid; j += kThreads) {
-        const uint64_t k = skeys[j];
-        const uint32_t d = digit_of(k, shift, mask);
-        const int64_t out = int64_t(goff[d]) + (j - int(digit_start[d]));
+        const uint64_t k = sh.skeys[j];
+        const uint32_t d = digit_of2<HI>(uint32_t(k), uint32_t(k >> 32), shift, mask);
+        const int64_t out = int64_t(uint32_t(sh.gdelta[d] + uint32_t(j)));
         kout[out] = k;
         if (PAIRS) vout[out] = svals[j];
+    }
+}
+
+template <bool PAIRS, bool TAG, int NB, bool HI>
+__global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
+                                                    const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
+                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag) {
+    __shared__ ScatterShared sh;
+    __shared__ float svals[PAIRS ? kTile : 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kWaves * kBins; i += kThreads) (&sh.cnt[0][0])[i] = 0;
+    uint32_t my_goff = 0;
+    if (tid < kBins) my_goff = offs[int64_t(blockIdx.x) * kBins + tid];
+    __syncthreads();
+    if (int64_t(blockIdx.x) * kTile + kTile <= n)
+        scatter_tile<PAIRS, TAG, NB, HI, true>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag);
+    else
+        scatter_tile<PAIRS, TAG, NB, HI, false>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag);
+}
+
+template <bool PAIRS, bool TAG>
+void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint64_t* b, const float* va, float* vb, int64_t n,
+                    int shift, uint32_t mask, int nb, const uint32_t* hist, const Tag& tag) {
+    const bool hi = shift >= 32;
+    // digits of 7 bits (42-bit keys in 6 passes) are matched with 7 ballots; every other width with 8 (the bits above
+    // the digit are zero in every lane and match trivially)
+    if (nb == 7) {
+        if (hi) scatter<PAIRS, TAG, 7, true><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
+        else scatter<PAIRS, TAG, 7, false><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
+    } else {
+        if (hi) scatter<PAIRS, TAG, 8, true><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
+        else scatter<PAIRS, TAG, 8, false><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
     }
 }
 
@@ -221,9 +350,9 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
         scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
         scan_chunks<<<1, kBins, 0, stream>>>(chunk, chunks);
         scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
-        if (pairs) scatter<true, false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, Tag{});
-        else if (tag && done == 0) scatter<false, true><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist, *tag);
-        else scatter<false, false><<<unsigned(tiles), kThreads, 0, stream>>>(a, b, nullptr, nullptr, n, shift, mask, hist, Tag{});
+        if (pairs) launch_scatter<true, false>(unsigned(tiles), stream, a, b, va, vb, n, shift, mask, nb, hist, Tag{});
+        else if (tag && done == 0) launch_scatter<false, true>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, *tag);
+        else launch_scatter<false, false>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, Tag{});
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         uint64_t* t = a; a = b; b = t;
