@@ -296,12 +296,12 @@ def row_variants(conv, K, nnz_total, dev, multi, steps=3):
         ev, issue = part.wait_events, part.issue_seconds
         part.wait_events = part.issue_seconds = None
         waits = [a.elapsed_time(b) for a, b in ev]
-        per_order = None
-        if len(waits) == K * steps and K > 0:
-            w = torch.tensor([sum(waits[i::K]) / steps for i in range(K)], device=dev, dtype=torch.float64)
-            if dist.is_initialized():
-                D.all_reduce(w, op=dist.ReduceOp.MAX)
-            per_order = w.tolist()
+        # every rank takes part in the reduction whatever it recorded (a rank without halo records no wait)
+        mine = [sum(waits[i::K]) / steps for i in range(K)] if (len(waits) == K * steps and K > 0) else [0.0] * K
+        w = torch.tensor(mine + [float(len(waits))], device=dev, dtype=torch.float64)
+        if dist.is_initialized():
+            D.all_reduce(w, op=dist.ReduceOp.MAX)
+        per_order = w[:K].tolist() if w[K].item() > 0 else None
         out[mode] = {'ms_per_step': t / steps * 1e3, 'edges_per_s': nnz_total * K / (t / steps),
                      'exposed_wait_ms_per_order': per_order,
                      'exposed_wait_ms_per_step': None if per_order is None else sum(per_order),

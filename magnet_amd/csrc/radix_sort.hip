@@ -188,6 +188,7 @@ struct ScatterShared {
     uint32_t cnt[kWaves][kBins];
     uint32_t digit_start[kBins];
     uint32_t gdelta[kBins];          // global offset of a digit's run minus its start inside the tile
+    uint32_t wave_total[kBins / 64];
     uint64_t skeys[kTile];
 };
 
@@ -248,17 +249,24 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
         sh.digit_start[tid] = run;
     }
     __syncthreads();
-    {                                      // exclusive scan of the 256 tile counts
+    {                                      // exclusive scan of the 256 tile counts: shuffle scan per wave, 4 wave totals
         uint32_t v = 0, inc = 0;
-        if (tid < kBins) { v = sh.digit_start[tid]; inc = v; }
-        for (int off = 1; off < kBins; off <<= 1) {
-            uint32_t t = (tid < kBins && tid >= off) ? sh.digit_start[tid - off] : 0u;
-            __syncthreads();
-            if (tid < kBins) { inc = sh.digit_start[tid] + t; sh.digit_start[tid] = inc; }
-            __syncthreads();
-        }
         if (tid < kBins) {
-            const uint32_t start = inc - v;
+            v = sh.digit_start[tid];
+            inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            if (lane == 63) sh.wave_total[w] = inc;
+        }
+        __syncthreads();
+        if (tid < kBins) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int ww = 0; ww < kBins / 64; ++ww) before += ww < w ? sh.wave_total[ww] : 0u;
+            const uint32_t start = before + inc - v;
             sh.gdelta[tid] = my_goff - start;
 #pragma unroll
             for (int ww = 0; ww < kWaves; ++ww) sh.cnt[ww][tid] += start;     // slot of (wave, digit) inside the tile
@@ -275,14 +283,19 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
         }
     }
     __syncthreads();
-    const int64_t left = n - tile_base;
-    const int n_valid = FULL ? kTile : int(left);
-    for (int j = tid; j < n_valid; j += kThreads) {
-        const uint64_t k = sh.skeys[j];
-        const uint32_t d = digit_of2<HI>(uint32_t(k), uint32_t(k >> 32), shift, mask);
-        const int64_t out = int64_t(uint32_t(sh.gdelta[d] + uint32_t(j)));
-        kout[out] = k;
-        if (PAIRS) vout[out] = svals[j];
+    // the digit-sorted tile to global memory, in runs of equal digit (fixed trip count: the LDS reads and the stores of
+    // a full tile are issued in batches)
+    const int n_valid = FULL ? kTile : int(n - tile_base);
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int j = i * kThreads + tid;
+        if (FULL || j < n_valid) {
+            const uint64_t k = sh.skeys[j];
+            const uint32_t d = digit_of2<HI>(uint32_t(k), uint32_t(k >> 32), shift, mask);
+            const int64_t out = int64_t(uint32_t(sh.gdelta[d] + uint32_t(j)));
+            kout[out] = k;
+            if (PAIRS) vout[out] = svals[j];
+        }
     }
 }
 
