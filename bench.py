@@ -81,21 +81,23 @@ def compulsory_bytes(nnz, n_rows, f, n_addends):
 
 def builder_bytes(e, n, nnz, passes):
     """Bytes the Laplacian builder streams for E edges (m = 2E directed records of 8 bytes, unweighted, int32 ids):
-    records (row and col read once per direction, m keys written), `passes` radix passes (histogram read + scatter
-    read + write of the keys), the binary searches for the group starts (their probes share cache lines; counted as
-    the N + 1 words they write, twice), segments (keys read, one flag byte written per record), flag scan (flags read
-    twice, a 4-byte slot written per record), emission (keys, flags and slots read; column and value, 12 bytes per
-    nonzero, written).  Runs longer than 64 records of one directed pair go through a side list (not counted: none on
-    this workload).  d^-1/2 of an entry's column comes from the record count its key carries (unweighted whole-graph
-    builds with whole column passes; a random 4-byte read per nonzero otherwise, not counted)."""
+    `passes` radix passes of histogram read + scatter read + write (the first pass reads the edge lists, 8 bytes per
+    record, and makes the records on the fly: no unsorted record is ever written), the binary searches for the group
+    starts (their probes share cache lines; counted as the N + 1 words they write, twice), segments (keys read, one
+    flag BIT written per record), the scan of the flag words (read twice, one 4-byte prefix written per 64 records),
+    row_ptr (N + 1 lookups of a prefix and a flag word, N + 1 words written), emission (keys, flag words and prefixes
+    read; column and value, 12 bytes per nonzero, written).  Runs longer than 64 records of one directed pair go through
+    a side list (not counted: none on this workload).  d^-1/2 of an entry's column comes from the record count its key
+    carries (unweighted whole-graph builds with whole column passes; a random 4-byte read per nonzero otherwise, not
+    counted)."""
     m = 2 * e
-    records = 2 * 8 * e + 8 * m
     sort = passes * 24 * m
     starts = 8 * (n + 1)
-    segments = 8 * m + m
-    flag_scan = 2 * m + 4 * m
-    emission = 8 * m + m + 4 * m + 12 * nnz
-    return records + sort + starts + segments + flag_scan + emission
+    segments = 8 * m + m // 8
+    flag_scan = 2 * (m // 8) + m // 16
+    row_ptr = 20 * (n + 1)
+    emission = 8 * m + m // 8 + m // 16 + 12 * nnz
+    return sort + starts + segments + flag_scan + row_ptr + emission
 
 
 def file_sha256(path):

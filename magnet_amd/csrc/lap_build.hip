@@ -6,7 +6,8 @@
 //
 //   1. every input edge (i, j, w) becomes two directed 64-bit records
 //        key = row << (cb+1) | col << 1 | dir       (cb = bits of n_nodes-1)
-//      (i, j, dir=0) "forward" and (j, i, dir=1) "backward";
+//      (i, j, dir=0) "forward" and (j, i, dir=1) "backward"; the records are made inside the first pass of the
+//      sort (its histogram and its scatter read the edge lists), so they are never written unsorted;
 //   2. one stable LSD radix sort over the 2*cb live (row, col) key bits (radix_sort.hip: tile histograms,
 //      column scan, ballot-match ranking; duplicate edges keep their input order).  Unweighted whole-graph
 //      builds whose column digits fill whole passes stop once after the column passes, when the records are
@@ -18,9 +19,9 @@
 //      s = (w_fwd + w_bwd)/2, delta = w_fwd - w_bwd, keep = (delta != 0 && s != 0);
 //   4. degrees d_row = sum_col s (fp64 over the row's records, or half the record count
 //      when unweighted), d == 0 -> 1, dinv = d^-1/2;
-//   5. exclusive scan of the keep flags (wavefront shuffle scan inside 4096-flag tiles,
-//      tile sums scanned by one workgroup) gives every kept entry its CSR slot and every
-//      row its row_ptr;
+//   5. the keep flags are one bit per record (a wavefront's ballot = one 64-bit word per 64 records); an exclusive
+//      scan of the words' population counts gives every word its first CSR slot, and a record's slot is that plus
+//      the set bits below it in its word - no per-record flag or slot array exists;
 //   6. emission: col_idx, val = -(2/lmax) * cis(fl32(fl32(2 pi q) * delta)) * ((dinv_r * s) * dinv_c),
 //      plus the diagonal (2/lmax - 1) when lmax != 2.
 //
@@ -38,10 +39,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-using mhscan::kScanTile;
-using mhscan::scan_tile_sums;
 using mhscan::scan_tiles;
-using mhscan::scan_tile_write;
 
 constexpr int kLongRun = 64;          // (row, col) runs longer than this are summed by a whole wavefront
 constexpr int kTagBits = 15;          // spare key bits that carry a column's record count (tagged keys)
@@ -53,13 +51,17 @@ struct Header {          // first 256 bytes of the workspace
     int64_t kept;        // number of kept off-diagonal entries
 };
 
+constexpr int kWordsPerThread = 8;
+constexpr int kWordTile = kBlock * kWordsPerThread;      // 2048 flag words (131072 records) per workgroup of the scan
+
 struct Layout {
     int64_t m;           // directed records
-    int64_t m_pad;       // m rounded up to the scan tile
-    int64_t n_tiles;
+    int64_t m_pad;       // m rounded up to a multiple of 4096 records (the two key buffers then lie 32 KiB-aligned apart)
+    int64_t n_words;     // 64-bit flag words incl. padding: a multiple of kWordTile covering positions 0..m
+    int64_t n_tiles;     // n_words / kWordTile
     int cb;              // bits per node id
-    size_t off_hdr, off_keys0, off_keys1, off_w0, off_w1, off_flags, off_pos, off_recptr, off_dinv,
-        off_tiles, off_long, off_sort, sort_bytes, total;
+    size_t off_hdr, off_keys0, off_keys1, off_w0, off_w1, off_bits, off_wpos, off_recptr, off_dinv,
+        off_tiles, off_long, off_tagtab, off_sort, sort_bytes, total;
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -74,8 +76,9 @@ int node_bits(int32_t n_nodes) {
 Layout make_layout(int64_t m, int32_t n_nodes, bool weighted) {
     Layout L{};
     L.m = m;
-    L.n_tiles = L.m / kScanTile + 1;              // covers positions 0..m (pos[m] = total)
-    L.m_pad = L.n_tiles * kScanTile;
+    L.m_pad = (m / 4096 + 1) * 4096;
+    L.n_tiles = (m / 64 + 1 + kWordTile - 1) / kWordTile;      // words 0 .. m / 64 (position m needs its word)
+    L.n_words = L.n_tiles * kWordTile;
     L.cb = node_bits(n_nodes);
     size_t o = 0;
     L.off_hdr = o;      o += 256;
@@ -83,12 +86,13 @@ Layout make_layout(int64_t m, int32_t n_nodes, bool weighted) {
     L.off_keys1 = o;    o += align_up(size_t(L.m_pad) * 8);
     L.off_w0 = o;       o += weighted ? align_up(size_t(L.m_pad) * 4) : 0;
     L.off_w1 = o;       o += weighted ? align_up(size_t(L.m_pad) * 4) : 0;
-    L.off_flags = o;    o += align_up(size_t(L.m_pad));
-    L.off_pos = o;      o += align_up(size_t(L.m_pad + 1) * 4);
+    L.off_bits = o;     o += align_up(size_t(L.n_words) * 8);
+    L.off_wpos = o;     o += align_up(size_t(L.n_words) * 4);
     L.off_recptr = o;   o += align_up(size_t(n_nodes + 1) * 4);
     L.off_dinv = o;     o += align_up(size_t(n_nodes) * 4 + 4);
     L.off_tiles = o;    o += align_up(size_t(L.n_tiles + 1) * 4);
     L.off_long = o;     o += align_up(size_t(L.m / (kLongRun + 1) + 1) * 4);
+    L.off_tagtab = o;   o += align_up(size_t(kTagCap) * 4);
     L.off_sort = o;
     L.sort_bytes = mhsort::workspace_bytes(L.m > 0 ? L.m : 1);
     o += align_up(L.sort_bytes);
@@ -105,37 +109,6 @@ inline bool use_tags(const Layout& L, bool weighted, bool whole_graph) {
 
 inline int64_t full_records(int64_t n_edges, int32_t n_nodes, bool gcn) {
     return 2 * (n_edges + (gcn ? int64_t(n_nodes) : 0));
-}
-
-// ---------------------------------------------------------------------------
-// 1. records of ONE direction: edge e = (i, j, w) of the list, or the self-loop (e - n_in, e - n_in, 1) for
-// n_in <= e < n_in + n_self (gcn_appr, hermitian.py:144-145), becomes the forward record (i, j, dir 0) or,
-// with swap, the backward record (j, i, dir 1).  A record's row must lie in [row_lo, row_hi).
-// ---------------------------------------------------------------------------
-template <typename IdxT>
-__global__ void __launch_bounds__(kBlock) make_records(const IdxT* __restrict__ row, const IdxT* __restrict__ col,
-                                                      const float* __restrict__ weight, int64_t n_in, int64_t n_self,
-                                                      int swap, int32_t n_nodes, int32_t row_lo, int32_t row_hi, int cb,
-                                                      uint64_t* __restrict__ keys, float* __restrict__ w_out,
-                                                      Header* hdr) {
-    int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (e >= n_in + n_self) return;
-    int64_t i, j;
-    float w = 1.0f;
-    if (e < n_in) {
-        i = int64_t(row[e]); j = int64_t(col[e]);
-        if (weight) w = weight[e];
-    } else {
-        i = j = e - n_in;
-    }
-    if (i < 0 || j < 0 || i >= n_nodes || j >= n_nodes) {
-        atomicOr(&hdr->err, 1);    // flag only; the record is made harmless below
-        i = j = row_lo; w = 0.0f;
-    }
-    const int64_t r = swap ? j : i, c = swap ? i : j;
-    if (r < row_lo || r >= row_hi) atomicOr(&hdr->err, 2);
-    keys[e] = (uint64_t(r) << (cb + 1)) | (uint64_t(c) << 1) | (swap ? 1ull : 0ull);
-    if (w_out) w_out[e] = w;
 }
 
 // ---------------------------------------------------------------------------
@@ -181,6 +154,13 @@ __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_weighted(const int32_t
     if (lane == 0) dinv[r] = inv_sqrt_degree(part);
 }
 
+// d^-1/2 for every record count a tagged key can carry (the emission looks a column's value up here instead of
+// repeating the double-precision square root and division per entry; same function, same bits)
+__global__ void __launch_bounds__(kBlock) tag_table_kernel(float* __restrict__ table) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < kTagCap) table[t] = inv_sqrt_degree(double(t));
+}
+
 // unweighted: every record has weight 1, so the degree is half the row's record count
 __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_counts(const int32_t* __restrict__ rec_ptr,
                                                                  int32_t n_nodes, float* __restrict__ dinv) {
@@ -204,56 +184,131 @@ __device__ inline uint8_t segment_kept(float s, float d) {
     return (d != 0.0f && s != 0.0f) ? 1 : 0;       // exact zeros are not stored by the CSR binops
 }
 
-// Walks the run of records that starts at p (key k) for at most kLongRun records, adding the weights side by side in
-// stored order.  Returns false when the run is longer than that (its sums then come from segments_long).
-__device__ inline bool walk_run(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted, int64_t m, int64_t p,
-                                uint64_t k, float& fwd, float& bwd) {
-    const uint64_t pair = k >> 1;
-    fwd = 0.0f; bwd = 0.0f;
-    int64_t t = p;
-    uint64_t kt = k;
-    for (int step = 0; step < kLongRun; ++step) {
-        float w = w_sorted ? w_sorted[t] : 1.0f;
-        if (kt & 1ull) bwd += w; else fwd += w;
-        ++t;
-        if (t >= m) return true;
-        kt = keys[t];
-        if ((kt >> 1) != pair) return true;
-    }
-    return false;
+// CSR slot of record p: kept records before its word (scan of the words' population counts) + set bits below it
+__device__ inline uint32_t slot_of(const uint64_t* __restrict__ bits, const uint32_t* __restrict__ word_pos, int64_t p) {
+    const uint64_t below = (1ull << (p & 63)) - 1ull;
+    return word_pos[p >> 6] + uint32_t(__popcll(bits[p >> 6] & below));
 }
 
-// Short runs leave only their keep flag here: the emission walks the (at most kLongRun) records again, from lines the
-// neighbouring threads have just brought into the caches, which is cheaper than writing s and delta for 400M records
-// and reading them back.  Long runs get their sums from segments_long, stored at the head's index in seg_s / seg_d.
-__global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
-                                                   int64_t m, uint8_t* __restrict__ flags, uint32_t* __restrict__ long_list,
-                                                   Header* hdr) {
-    int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= m) return;
-    uint64_t k = keys[p];
-    bool head = (p == 0) || ((keys[p - 1] >> 1) != (k >> 1));
-    uint8_t keep = 0;
-    if (head) {
-        float fwd, bwd, s, d;
-        if (walk_run(keys, w_sorted, m, p, k, fwd, bwd)) {
-            segment_values(fwd, bwd, s, d);
-            keep = segment_kept(s, d);
-        } else {
-            long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag written by segments_long
+// What a wavefront knows about the runs among its 64 consecutive records p = base + lane, from three ballots: which
+// lanes hold a record (a prefix), which records start a (row, col) run, which are backward records.
+struct WaveRuns {
+    uint64_t in_mask, head_mask, dir_mask;
+    uint64_t next_key;       // the record after the wave's 64 (read up front, beside the wave's own records)
+    bool has_next;
+};
+
+// k / in = the lane's record and whether p < m; every lane of the wave calls this
+__device__ inline WaveRuns wave_runs(const uint64_t* __restrict__ keys, int64_t m, int64_t p, int lane, uint64_t k, bool in,
+                                     bool& head) {
+    WaveRuns r;
+    const int64_t after = p - lane + 64;
+    r.has_next = after < m;
+    r.next_key = r.has_next ? keys[after] : 0ull;
+    const uint32_t plo = __shfl_up(uint32_t(k), 1, 64), phi = __shfl_up(uint32_t(k >> 32), 1, 64);
+    uint64_t prev = (uint64_t(phi) << 32) | plo;
+    if (lane == 0 && p > 0 && in) prev = keys[p - 1];
+    head = in && (p == 0 || (prev >> 1) != (k >> 1));
+    r.in_mask = __ballot(in);
+    r.head_mask = __ballot(head);
+    r.dir_mask = __ballot(in && (k & 1ull));
+    return r;
+}
+
+// Sums of the run that starts at this lane's record (meaningful for run heads; every lane of the wave calls this, `want`
+// says whether the lane needs its sums).  The run is walked in stored order, forward weights (dir bit 0) and backward
+// weights added separately - the fp32 sequence of the reference's duplicate summation.  Inside the wave the run's extent
+// comes from the ballots: unit weights are counted (exact in fp32), real weights arrive by lane shuffles; a run that
+// reaches the end of the wave is continued from memory.  Returns false when the run is longer than kLongRun records
+// (its sums then come from segments_long).
+__device__ inline bool run_sums(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted, int64_t m, int64_t p,
+                                int lane, uint64_t k, float w, const WaveRuns& r, bool want, float& fwd, float& bwd) {
+    int end, len;
+    if (r.head_mask == r.in_mask) {
+        // every record of the wave is a run of its own (the usual case: duplicate edges are rare) - wave-uniform test
+        end = lane == 63 ? 64 : lane + 1;
+        len = 1;
+        fwd = (k & 1ull) ? 0.0f : w;
+        bwd = (k & 1ull) ? w : 0.0f;
+    } else if (!w_sorted) {
+        const uint64_t above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        const uint64_t stop = (r.head_mask | ~r.in_mask) & above;     // the next run, or the end of the records
+        end = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+        const uint64_t range = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+        len = end - lane;
+        fwd = float(__popcll(range & ~r.dir_mask));
+        bwd = float(__popcll(range & r.dir_mask));
+    } else {
+        const uint64_t above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        const uint64_t stop = (r.head_mask | ~r.in_mask) & above;
+        end = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+        len = end - lane;
+        fwd = (k & 1ull) ? 0.0f : w;
+        bwd = (k & 1ull) ? w : 0.0f;
+        int longest = want ? len : 0;                   // the longest wanted run of the wave
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(longest, off, 64); longest = o > longest ? o : longest; }
+        longest = __builtin_amdgcn_readfirstlane(longest);
+        for (int j = 1; j < longest; ++j) {             // wave-uniform trip count
+            const float nw = __shfl_down(w, j, 64);
+            if (want && lane + j < end) {
+                if ((r.dir_mask >> (lane + j)) & 1ull) bwd += nw; else fwd += nw;
+            }
         }
     }
-    flags[p] = keep;
+    const uint64_t pair = k >> 1;
+    if (want && end == 64 && r.has_next && (r.next_key >> 1) == pair) {   // the run continues past the wave: from memory
+        int64_t t = p - lane + 64;
+        while (t < m) {
+            const uint64_t kt = keys[t];
+            if ((kt >> 1) != pair) break;
+            if (len == kLongRun) return false;
+            const float wt = w_sorted ? w_sorted[t] : 1.0f;
+            if (kt & 1ull) bwd += wt; else fwd += wt;
+            ++len; ++t;
+        }
+    }
+    return true;
+}
+
+// Keep flags, one bit per record: a short run's head computes its sums and the keep rule; the wave's ballot is the flag
+// word of its 64 records.  Nothing else is stored for short runs: the emission walks them again (from its own registers),
+// which is cheaper than writing s and delta for every record and reading them back.  Long runs go on a list; their flag
+// bit is set by segments_long.
+__global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
+                                                   int64_t m, uint64_t* __restrict__ bits, uint32_t* __restrict__ long_list,
+                                                   Header* hdr) {
+    const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (p - lane >= m) return;                          // the whole wavefront lies past the records
+    const bool in = p < m;
+    const uint64_t k = in ? keys[p] : 0ull;
+    const float w = (in && w_sorted) ? w_sorted[p] : 1.0f;
+    bool head;
+    const WaveRuns runs = wave_runs(keys, m, p, lane, k, in, head);
+    float fwd, bwd;
+    const bool is_short = run_sums(keys, w_sorted, m, p, lane, k, w, runs, head, fwd, bwd);
+    bool keep = false;
+    if (head) {
+        if (is_short) {
+            float sv, dv;
+            segment_values(fwd, bwd, sv, dv);
+            keep = segment_kept(sv, dv) != 0;
+        } else {
+            long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag bit set by segments_long
+        }
+    }
+    const uint64_t word = __ballot(keep);
+    if (lane == 0) bits[p >> 6] = word;
 }
 
 // One wavefront per long run, 64 records per step: the lanes load the step's records side by side (coalesced),
-// then the weights are added in stored order, the same fp32 sequence the single-thread walk of a short run
+// then the weights are added in stored order, the same fp32 sequence the walk of a short run
 // performs (every lane carries the same running sums), at one shuffle + add per record instead of one
 // dependent memory access per record.  Unweighted runs are counted.
 // The grid is fixed; the waves stride over the list whose length the kernel before left in the header.
 __global__ void __launch_bounds__(kBlock) segments_long(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
                                                         int64_t m, float* __restrict__ seg_s, float* __restrict__ seg_d,
-                                                        uint8_t* __restrict__ flags, const uint32_t* __restrict__ long_list,
+                                                        uint64_t* __restrict__ bits, const uint32_t* __restrict__ long_list,
                                                         const Header* hdr) {
     const int lane = threadIdx.x & 63;
     const int n_long = hdr->n_long;
@@ -287,45 +342,88 @@ __global__ void __launch_bounds__(kBlock) segments_long(const uint64_t* __restri
             float sv, dv;
             segment_values(fwd, bwd, sv, dv);
             seg_s[p] = sv; seg_d[p] = dv;
-            flags[p] = segment_kept(sv, dv);
+            if (segment_kept(sv, dv)) atomicOr(reinterpret_cast<unsigned long long*>(bits + (p >> 6)), 1ull << (p & 63));
         }
     }
 }
 
-// row_ptr of the rows [row_lo, row_hi]: CSR slot of the row's first kept entry (+ one diagonal per earlier row)
-__global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restrict__ rec_ptr, const uint32_t* __restrict__ pos,
-                                                        int32_t row_lo, int32_t row_hi, int diag, int32_t* __restrict__ row_ptr) {
+// Scan of the flag words' population counts: word_pos[i] = kept records before word i.  Tile sums, one workgroup over
+// the tile sums (mhscan::scan_tiles), then the words' prefixes.
+__global__ void __launch_bounds__(kBlock) word_tile_sums(const uint64_t* __restrict__ bits, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t wsum[kBlock / 64];
+    const uint64_t* b = bits + size_t(blockIdx.x) * kWordTile + size_t(threadIdx.x) * kWordsPerThread;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i) v += uint32_t(__popcll(b[i]));
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(kBlock) word_tile_write(const uint64_t* __restrict__ bits, const uint32_t* __restrict__ tile_sums,
+                                                         uint32_t* __restrict__ word_pos) {
+    __shared__ uint32_t wtot[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = size_t(blockIdx.x) * kWordTile + size_t(threadIdx.x) * kWordsPerThread;
+    uint32_t c[kWordsPerThread], tsum = 0;
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i) { c[i] = uint32_t(__popcll(bits[base + i])); tsum += c[i]; }
+    uint32_t inc = mhscan::wave_inclusive_scan(tsum, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t off = tile_sums[blockIdx.x] + inc - tsum;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i) { word_pos[base + i] = off; off += c[i]; }
+}
+
+// row_ptr of the rows [row_lo, row_hi]: CSR slot of the row's first record (+ one diagonal per earlier row)
+__global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restrict__ rec_ptr, const uint64_t* __restrict__ bits,
+                                                        const uint32_t* __restrict__ word_pos, int32_t row_lo, int32_t row_hi,
+                                                        int diag, int32_t* __restrict__ row_ptr) {
     int64_t r = int64_t(row_lo) + int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (r > row_hi) return;
-    row_ptr[r - row_lo] = int32_t(pos[rec_ptr[r]]) + (diag ? int32_t(r - row_lo) : 0);
+    row_ptr[r - row_lo] = int32_t(slot_of(bits, word_pos, rec_ptr[r])) + (diag ? int32_t(r - row_lo) : 0);
 }
 
 // ---------------------------------------------------------------------------
-// 6. emission
+// 6. emission: a wavefront takes the 64 records of one flag word
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
-                                                       const uint8_t* __restrict__ flags,
-                                                       const uint32_t* __restrict__ pos, const float* __restrict__ seg_s,
+                                                       const uint64_t* __restrict__ bits,
+                                                       const uint32_t* __restrict__ word_pos, const float* __restrict__ seg_s,
                                                        const float* __restrict__ seg_d, const float* __restrict__ dinv,
+                                                       const float* __restrict__ tag_table,
                                                        int64_t m, int cb, int32_t row_lo, float two_pi_q, float scale, int diag,
                                                        int64_t nnz, int tagged, int32_t* __restrict__ col_idx,
                                                        float2* __restrict__ val) {
-    int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= m || !flags[p]) return;
-    uint64_t k = keys[p];
+    const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (p - lane >= m) return;
+    const uint64_t word = bits[p >> 6];
+    if (word == 0ull) return;                           // no kept entry among these 64 records
+    const bool in = p < m;
+    const uint64_t k = in ? keys[p] : 0ull;
+    const float w = (in && w_sorted) ? w_sorted[p] : 1.0f;
+    const bool kept = (word >> lane) & 1ull;            // kept entries are run heads
+    bool head;
+    const WaveRuns runs = wave_runs(keys, m, p, lane, k, in, head);
+    float fwd, bwd, sv, dv;
+    const bool is_short = run_sums(keys, w_sorted, m, p, lane, k, w, runs, kept, fwd, bwd);
+    if (!kept) return;
+    if (is_short) segment_values(fwd, bwd, sv, dv);
+    else { sv = seg_s[p]; dv = seg_d[p]; }              // a long run: summed by segments_long
     const uint64_t node_mask = (1ull << cb) - 1ull;
     int32_t r = int32_t((k >> (cb + 1)) & node_mask);
     int32_t c = int32_t((k >> 1) & node_mask);
-    int64_t idx = int64_t(pos[p]);
+    int64_t idx = int64_t(word_pos[p >> 6]) + int64_t(__popcll(word & ((1ull << lane) - 1ull)));
     if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
     if (idx >= nnz) return;                            // caller's arrays are shorter than the count phase reported
     float dc;
     const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
-    if (tag < kTagCap) dc = inv_sqrt_degree(double(tag));     // the column's record count travelled in the key
+    if (tag < kTagCap) dc = tag_table[tag];            // the column's record count travelled in the key
     else dc = dinv[c];
-    float fwd, bwd, sv, dv;
-    if (walk_run(keys, w_sorted, m, p, k, fwd, bwd)) segment_values(fwd, bwd, sv, dv);
-    else { sv = seg_s[p]; dv = seg_d[p]; }             // a long run: summed by segments_long
     float a = (dinv[r] * sv) * dc;                     // (D A_s) D, hermitian.py:154
     float theta = two_pi_q * dv;                       // fp32 product, hermitian.py:157
     float sn, cs;
@@ -336,7 +434,8 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
 }
 
 // diagonal (2/lmax - 1) of every row of the block; its slot follows the row's kept entries with col < r
-__global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
+__global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ bits,
+                                                        const uint32_t* __restrict__ word_pos,
                                                         int64_t m, int32_t row_lo, int32_t row_hi, int cb, float diag_val,
                                                         int64_t nnz, int32_t* __restrict__ col_idx, float2* __restrict__ val) {
     int64_t r = int64_t(row_lo) + int64_t(blockIdx.x) * kBlock + threadIdx.x;
@@ -348,7 +447,7 @@ __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restri
         int64_t mid = (lo + hi) >> 1;
         if ((keys[mid] & live) < target) lo = mid + 1; else hi = mid;
     }
-    int64_t idx = int64_t(pos[lo]) + (r - row_lo);
+    int64_t idx = int64_t(slot_of(bits, word_pos, lo)) + (r - row_lo);
     if (idx >= nnz) return;
     col_idx[idx] = int32_t(r);
     val[idx] = make_float2(diag_val, 0.0f);
@@ -357,8 +456,8 @@ __global__ void __launch_bounds__(kBlock) emit_diagonal(const uint64_t* __restri
 inline unsigned grid_for(int64_t n) { return unsigned((n + kBlock - 1) / kBlock); }
 
 struct Work {            // the workspace cut up
-    Header* hdr; uint64_t *keys0, *keys1; float *w0, *w1; uint8_t* flags; uint32_t* pos; int32_t* rec_ptr; float* dinv;
-    uint32_t* tiles; uint32_t* long_list; char* sort;
+    Header* hdr; uint64_t *keys0, *keys1; float *w0, *w1; uint64_t* bits; uint32_t* word_pos; int32_t* rec_ptr; float* dinv;
+    uint32_t* tiles; uint32_t* long_list; float* tag_table; char* sort;
 };
 
 Work cut(void* workspace, const Layout& L, bool weighted) {
@@ -369,12 +468,13 @@ Work cut(void* workspace, const Layout& L, bool weighted) {
     w.keys1 = reinterpret_cast<uint64_t*>(ws + L.off_keys1);
     w.w0 = weighted ? reinterpret_cast<float*>(ws + L.off_w0) : nullptr;
     w.w1 = weighted ? reinterpret_cast<float*>(ws + L.off_w1) : nullptr;
-    w.flags = reinterpret_cast<uint8_t*>(ws + L.off_flags);
-    w.pos = reinterpret_cast<uint32_t*>(ws + L.off_pos);
+    w.bits = reinterpret_cast<uint64_t*>(ws + L.off_bits);
+    w.word_pos = reinterpret_cast<uint32_t*>(ws + L.off_wpos);
     w.rec_ptr = reinterpret_cast<int32_t*>(ws + L.off_recptr);
     w.dinv = reinterpret_cast<float*>(ws + L.off_dinv);
     w.tiles = reinterpret_cast<uint32_t*>(ws + L.off_tiles);
     w.long_list = reinterpret_cast<uint32_t*>(ws + L.off_long);
+    w.tag_table = reinterpret_cast<float*>(ws + L.off_tagtab);
     w.sort = ws + L.off_sort;
     return w;
 }
@@ -382,49 +482,38 @@ Work cut(void* workspace, const Layout& L, bool weighted) {
 struct EdgeList { const void* row; const void* col; const float* w; int64_t n; int64_t n_self; };
 
 // The sort key is (row, col) = key bits [1, 2cb+1).  The direction bit 0 is NOT sorted: all forward
-// records are written before all backward records and the sort is stable, so inside a (row, col)
+// records come before all backward records in the record order and the sort is stable, so inside a (row, col)
 // segment the forward records still come first, each side in input order.
-// An odd number of sort passes moves the records keys0 -> keys1; for an even number they start in keys1,
-// so that the sorted records always end in keys1 / w1.
+// The records are made by the sort's first pass (mhsort::RecordSource).  An odd number of passes moves them
+// "first buffer" -> keys1 when the pass that makes them writes into the buffer chosen here, so that the sorted
+// records always end in keys1 / w1.
 int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const EdgeList& bwd, int idx64, bool weighted,
                      bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream) {
+    if (L.m <= 0) return MH_OK;
     const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
-    uint64_t* rec_keys = start_in_0 ? W.keys0 : W.keys1;
+    uint64_t* rec_keys = start_in_0 ? W.keys0 : W.keys1;          // the buffer the first pass does NOT write
     float* rec_w = weighted ? (start_in_0 ? W.w0 : W.w1) : nullptr;
-    const EdgeList* lists[2] = {&fwd, &bwd};
-    int64_t at = 0;
-    for (int dir = 0; dir < 2; ++dir) {
-        const EdgeList& e = *lists[dir];
-        const int64_t cnt = e.n + e.n_self;
-        if (cnt == 0) continue;
-        if (idx64)
-            make_records<int64_t><<<grid_for(cnt), kBlock, 0, stream>>>(
-                static_cast<const int64_t*>(e.row), static_cast<const int64_t*>(e.col), e.w, e.n, e.n_self, dir, n_nodes,
-                row_lo, row_hi, L.cb, rec_keys + at, rec_w ? rec_w + at : nullptr, W.hdr);
-        else
-            make_records<int32_t><<<grid_for(cnt), kBlock, 0, stream>>>(
-                static_cast<const int32_t*>(e.row), static_cast<const int32_t*>(e.col), e.w, e.n, e.n_self, dir, n_nodes,
-                row_lo, row_hi, L.cb, rec_keys + at, rec_w ? rec_w + at : nullptr, W.hdr);
-        MH_LAUNCH_CHECK("make_records");
-        at += cnt;
+    uint64_t* other = rec_keys == W.keys0 ? W.keys1 : W.keys0;
+    float* other_w = weighted ? (rec_w == W.w0 ? W.w1 : W.w0) : nullptr;
+    mhsort::RecordSource src{};
+    src.row[0] = fwd.row; src.col[0] = fwd.col; src.w[0] = fwd.w; src.n_in[0] = fwd.n; src.n_self[0] = fwd.n_self;
+    src.row[1] = bwd.row; src.col[1] = bwd.col; src.w[1] = bwd.w; src.n_in[1] = bwd.n; src.n_self[1] = bwd.n_self;
+    src.idx64 = idx64; src.cb = L.cb; src.n_nodes = n_nodes; src.row_lo = row_lo; src.row_hi = row_hi;
+    src.err = &W.hdr->err;
+    if (!tagged) {
+        MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, W.sort, L.sort_bytes, stream, nullptr, &src));
+    } else {
+        // column passes; group sizes of the columns; row passes, the first of which writes the sizes into the keys
+        const uint64_t node_mask = (1ull << L.cb) - 1ull;
+        MH_HIP(mhsort::sort(rec_keys, other, nullptr, nullptr, L.m, 1, L.cb, W.sort, L.sort_bytes, stream, nullptr, &src));
+        uint64_t* by_col = (mhsort::passes_for(L.cb) & 1) ? other : rec_keys;
+        uint64_t* spare = by_col == rec_keys ? other : rec_keys;
+        row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(by_col, L.m, n_nodes, 1, node_mask, W.rec_ptr);
+        MH_LAUNCH_CHECK("column_starts");
+        const mhsort::Tag tag{W.rec_ptr, 1, uint32_t(node_mask), 2 * L.cb + 1, kTagCap};
+        MH_HIP(mhsort::sort(by_col, spare, nullptr, nullptr, L.m, L.cb + 1, L.cb, W.sort, L.sort_bytes, stream, &tag));
     }
-    if (L.m > 0) {
-        uint64_t* other = rec_keys == W.keys0 ? W.keys1 : W.keys0;
-        float* other_w = weighted ? (rec_w == W.w0 ? W.w1 : W.w0) : nullptr;
-        if (!tagged) {
-            MH_HIP(mhsort::sort(rec_keys, other, rec_w, other_w, L.m, 1, 2 * L.cb, W.sort, L.sort_bytes, stream));
-        } else {
-            // column passes; group sizes of the columns; row passes, the first of which writes the sizes into the keys
-            const uint64_t node_mask = (1ull << L.cb) - 1ull;
-            MH_HIP(mhsort::sort(rec_keys, other, nullptr, nullptr, L.m, 1, L.cb, W.sort, L.sort_bytes, stream));
-            uint64_t* by_col = (mhsort::passes_for(L.cb) & 1) ? other : rec_keys;
-            uint64_t* spare = by_col == rec_keys ? other : rec_keys;
-            row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(by_col, L.m, n_nodes, 1, node_mask, W.rec_ptr);
-            MH_LAUNCH_CHECK("column_starts");
-            const mhsort::Tag tag{W.rec_ptr, 1, uint32_t(node_mask), 2 * L.cb + 1, kTagCap};
-            MH_HIP(mhsort::sort(by_col, spare, nullptr, nullptr, L.m, L.cb + 1, L.cb, W.sort, L.sort_bytes, stream, &tag));
-        }
-    }
+    MH_LAUNCH_CHECK("sort");
     return MH_OK;
 }
 
@@ -448,18 +537,19 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int
     float* seg_s = reinterpret_cast<float*>(W.keys0);           // keys0 is free after the sort
     float* seg_d = seg_s + L.m_pad;
     if (L.m > 0) {
-        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, W.flags, W.long_list, W.hdr);
+        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, W.bits, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments");
-        segments_long<<<1024, kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.flags, W.long_list, W.hdr);
+        segments_long<<<1024, kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.bits, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments_long");
     }
-    scan_tile_sums<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.flags, W.tiles);
-    MH_LAUNCH_CHECK("scan_tile_sums");
+    word_tile_sums<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.bits, W.tiles);
+    MH_LAUNCH_CHECK("word_tile_sums");
     scan_tiles<<<1, 1024, 0, stream>>>(W.tiles, L.n_tiles, &W.hdr->kept);
     MH_LAUNCH_CHECK("scan_tiles");
-    scan_tile_write<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.flags, W.tiles, W.pos, L.m);
-    MH_LAUNCH_CHECK("scan_tile_write");
-    write_row_ptr<<<grid_for(int64_t(row_hi - row_lo) + 1), kBlock, 0, stream>>>(W.rec_ptr, W.pos, row_lo, row_hi, diag, row_ptr);
+    word_tile_write<<<unsigned(L.n_tiles), kBlock, 0, stream>>>(W.bits, W.tiles, W.word_pos);
+    MH_LAUNCH_CHECK("word_tile_write");
+    write_row_ptr<<<grid_for(int64_t(row_hi - row_lo) + 1), kBlock, 0, stream>>>(W.rec_ptr, W.bits, W.word_pos, row_lo, row_hi, diag,
+                                                                                 row_ptr);
     MH_LAUNCH_CHECK("write_row_ptr");
     if (dinv_block && row_hi > row_lo)
         MH_HIP(hipMemcpyAsync(dinv_block, W.dinv + row_lo, size_t(row_hi - row_lo) * 4, hipMemcpyDeviceToDevice, stream));
@@ -485,15 +575,19 @@ int fill_sorted(const Layout& L, const Work& W, bool tagged, int32_t row_lo, int
     if (L.m > 0 && nnz > 0) {
         MH_REQUIRE(col_idx && val, "col_idx/val is null");
         MH_REQUIRE((reinterpret_cast<uintptr_t>(val) & 7u) == 0, "val must be 8-byte aligned");
-        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, W.flags, W.pos, seg_s, seg_d, dinv, L.m, L.cb, row_lo,
+        if (tagged) {
+            tag_table_kernel<<<grid_for(kTagCap), kBlock, 0, stream>>>(W.tag_table);
+            MH_LAUNCH_CHECK("tag_table");
+        }
+        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, W.bits, W.word_pos, seg_s, seg_d, dinv, W.tag_table, L.m, L.cb, row_lo,
                                                            two_pi_q, scale, diag, nnz, tagged ? 1 : 0, col_idx,
                                                            reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_entries");
     }
     if (diag && row_hi > row_lo) {
         MH_REQUIRE(col_idx && val && nnz >= row_hi - row_lo, "col_idx/val is null or nnz too small for the diagonal");
-        emit_diagonal<<<grid_for(row_hi - row_lo), kBlock, 0, stream>>>(W.keys1, W.pos, L.m, row_lo, row_hi, L.cb, diag_val, nnz,
-                                                                        col_idx, reinterpret_cast<float2*>(val));
+        emit_diagonal<<<grid_for(row_hi - row_lo), kBlock, 0, stream>>>(W.keys1, W.bits, W.word_pos, L.m, row_lo, row_hi, L.cb,
+                                                                        diag_val, nnz, col_idx, reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_diagonal");
     }
     return MH_OK;
@@ -505,7 +599,7 @@ int prepare(const Layout& L, void* workspace, size_t workspace_bytes, const Work
         return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
     MH_REQUIRE(mh_aligned16(workspace), "workspace must be 16-byte aligned");
     MH_HIP(hipMemsetAsync(W.hdr, 0, 256, stream));
-    MH_HIP(hipMemsetAsync(W.flags, 0, size_t(L.m_pad), stream));
+    MH_HIP(hipMemsetAsync(W.bits, 0, size_t(L.n_words) * 8, stream));
     return MH_OK;
 }
 

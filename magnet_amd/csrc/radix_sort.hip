@@ -27,8 +27,43 @@ constexpr int kChunk = 256;                  // tiles per scan chunk
 
 __device__ inline uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return uint32_t(k >> shift) & mask; }
 
+// Record p of a RecordSource (see radix_sort.h); FLAG: report bad endpoints / rows in *err (done by one of the two
+// kernels that visit every record).
+template <typename IdxT, bool FLAG>
+__device__ inline uint64_t record_key(const RecordSource& g, int64_t p, float& w) {
+    const int64_t cnt0 = g.n_in[0] + g.n_self[0];
+    const int dir = p >= cnt0 ? 1 : 0;
+    const int64_t e = p - (dir ? cnt0 : 0);
+    int64_t i, j;
+    w = 1.0f;
+    if (e < g.n_in[dir]) {
+        i = int64_t(static_cast<const IdxT*>(g.row[dir])[e]);
+        j = int64_t(static_cast<const IdxT*>(g.col[dir])[e]);
+        if (g.w[dir]) w = g.w[dir][e];
+    } else {
+        i = j = e - g.n_in[dir];
+    }
+    if (i < 0 || j < 0 || i >= g.n_nodes || j >= g.n_nodes) {
+        if (FLAG) atomicOr(g.err, 1);      // flag only; the record is made harmless
+        i = j = g.row_lo; w = 0.0f;
+    }
+    const int64_t r = dir ? j : i, c = dir ? i : j;
+    if (FLAG && (r < g.row_lo || r >= g.row_hi)) atomicOr(g.err, 2);
+    return (uint64_t(r) << (g.cb + 1)) | (uint64_t(c) << 1) | uint64_t(dir);
+}
+
+// GEN: 0 = keys in memory, 1 / 2 = records made from int32 / int64 edge lists
+template <int GEN>
+__device__ inline uint64_t key_at(const uint64_t* __restrict__ keys, const RecordSource& g, int64_t idx) {
+    float w;
+    if (GEN == 1) return record_key<int32_t, false>(g, idx, w);
+    if (GEN == 2) return record_key<int64_t, false>(g, idx, w);
+    return keys[idx];
+}
+
+template <int GEN>
 __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                           uint32_t mask, uint32_t* __restrict__ hist) {
+                                                           uint32_t mask, uint32_t* __restrict__ hist, const RecordSource gen) {
     __shared__ uint32_t bins[kBins];
     if (threadIdx.x < kBins) bins[threadIdx.x] = 0;
     __syncthreads();
@@ -36,7 +71,7 @@ __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __res
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         int64_t idx = base + i * kThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&bins[digit_of(keys[idx], shift, mask)], 1u);
+        if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < kBins) hist[int64_t(blockIdx.x) * kBins + threadIdx.x] = bins[threadIdx.x];
@@ -194,10 +229,11 @@ struct ScatterShared {
 
 // One tile of a pass.  FULL: no key of the tile is out of range (every tile but the last).  NB: digit bits that are
 // matched (8, or 7 for the 7-bit digits of 42-bit keys).  HI: see digit_of2.
-template <bool PAIRS, bool TAG, int NB, bool HI, bool FULL>
+template <bool PAIRS, bool TAG, int NB, bool HI, bool FULL, int GEN>
 __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint64_t* __restrict__ kin,
                                     uint64_t* __restrict__ kout, const float* __restrict__ vin, float* __restrict__ vout,
-                                    int64_t n, int shift, uint32_t mask, uint32_t my_goff, const Tag& tag) {
+                                    int64_t n, int shift, uint32_t mask, uint32_t my_goff, const Tag& tag,
+                                    const RecordSource& gen) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t tile_base = int64_t(blockIdx.x) * kTile;
     const int64_t chunk_base = tile_base + int64_t(w) * (64 * kItems);
@@ -208,8 +244,15 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
     for (int i = 0; i < kItems; ++i) {
         int64_t idx = chunk_base + i * 64 + lane;
         bool ok = FULL || idx < n;
-        key[i] = ok ? kin[idx] : ~0ull;
-        if (PAIRS) val[i] = ok ? vin[idx] : 0.f;
+        if (GEN != 0) {
+            float wv = 0.f;
+            key[i] = ~0ull;
+            if (ok) key[i] = GEN == 1 ? record_key<int32_t, true>(gen, idx, wv) : record_key<int64_t, true>(gen, idx, wv);
+            if (PAIRS) val[i] = wv;
+        } else {
+            key[i] = ok ? kin[idx] : ~0ull;
+            if (PAIRS) val[i] = ok ? vin[idx] : 0.f;
+        }
         if (TAG && ok) {
             // the keys arrive grouped by the field, so neighbouring lanes read the same few entries of starts[]
             const uint32_t f = uint32_t(key[i] >> tag.field_shift) & tag.field_mask;
@@ -299,10 +342,11 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
     }
 }
 
-template <bool PAIRS, bool TAG, int NB, bool HI>
+template <bool PAIRS, bool TAG, int NB, bool HI, int GEN>
 __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                     const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
-                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag) {
+                                                    int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag,
+                                                    const RecordSource gen) {
     __shared__ ScatterShared sh;
     __shared__ float svals[PAIRS ? kTile : 1];
     const int tid = threadIdx.x;
@@ -311,24 +355,33 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
     if (tid < kBins) my_goff = offs[int64_t(blockIdx.x) * kBins + tid];
     __syncthreads();
     if (int64_t(blockIdx.x) * kTile + kTile <= n)
-        scatter_tile<PAIRS, TAG, NB, HI, true>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag);
+        scatter_tile<PAIRS, TAG, NB, HI, true, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen);
     else
-        scatter_tile<PAIRS, TAG, NB, HI, false>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag);
+        scatter_tile<PAIRS, TAG, NB, HI, false, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen);
 }
 
 template <bool PAIRS, bool TAG>
 void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint64_t* b, const float* va, float* vb, int64_t n,
                     int shift, uint32_t mask, int nb, const uint32_t* hist, const Tag& tag) {
     const bool hi = shift >= 32;
+    const RecordSource none{};
     // digits of 7 bits (42-bit keys in 6 passes) are matched with 7 ballots; every other width with 8 (the bits above
     // the digit are zero in every lane and match trivially)
     if (nb == 7) {
-        if (hi) scatter<PAIRS, TAG, 7, true><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
-        else scatter<PAIRS, TAG, 7, false><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
+        if (hi) scatter<PAIRS, TAG, 7, true, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
+        else scatter<PAIRS, TAG, 7, false, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
     } else {
-        if (hi) scatter<PAIRS, TAG, 8, true><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
-        else scatter<PAIRS, TAG, 8, false><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag);
+        if (hi) scatter<PAIRS, TAG, 8, true, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
+        else scatter<PAIRS, TAG, 8, false, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
     }
+}
+
+// first pass of a sort whose keys come from a record source (low key bits: HI is false)
+template <bool PAIRS, int GEN>
+void launch_scatter_gen(unsigned tiles, hipStream_t stream, uint64_t* b, float* vb, int64_t n, int shift, uint32_t mask, int nb,
+                        const uint32_t* hist, const RecordSource& gen) {
+    if (nb == 7) scatter<PAIRS, false, 7, false, GEN><<<tiles, kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen);
+    else scatter<PAIRS, false, 8, false, GEN><<<tiles, kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen);
 }
 
 inline size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
@@ -343,9 +396,9 @@ size_t workspace_bytes(int64_t n) {
 }
 
 hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int first_bit, int bits, void* workspace,
-                size_t ws_bytes, hipStream_t stream, const Tag* tag) {
+                size_t ws_bytes, hipStream_t stream, const Tag* tag, const RecordSource* gen) {
     if (n <= 0 || bits <= 0) return hipSuccess;
-    if (tag && va) return hipErrorInvalidValue;
+    if (tag && (va || gen)) return hipErrorInvalidValue;
     if (ws_bytes < workspace_bytes(n) || n >= (int64_t(1) << 32)) return hipErrorInvalidValue;
     const int64_t tiles = (n + kTile - 1) / kTile;
     const int64_t chunks = (tiles + kChunk - 1) / kChunk;
@@ -359,11 +412,24 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
         const int shift = first_bit + done;
         const int nb = bits - done < width ? bits - done : width;
         const uint32_t mask = (1u << nb) - 1u;
-        tile_histogram<<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist);
+        const bool from_source = gen != nullptr && done == 0;
+        if (from_source && shift + nb > 32) return hipErrorInvalidValue;
+        if (!from_source) tile_histogram<0><<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist, RecordSource{});
+        else if (gen->idx64) tile_histogram<2><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, *gen);
+        else tile_histogram<1><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, *gen);
         scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
         scan_chunks<<<1, kBins, 0, stream>>>(chunk, chunks);
         scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
-        if (pairs) launch_scatter<true, false>(unsigned(tiles), stream, a, b, va, vb, n, shift, mask, nb, hist, Tag{});
+        if (from_source) {
+            if (pairs) {
+                if (gen->idx64) launch_scatter_gen<true, 2>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
+                else launch_scatter_gen<true, 1>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
+            } else {
+                if (gen->idx64) launch_scatter_gen<false, 2>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
+                else launch_scatter_gen<false, 1>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
+            }
+        }
+        else if (pairs) launch_scatter<true, false>(unsigned(tiles), stream, a, b, va, vb, n, shift, mask, nb, hist, Tag{});
         else if (tag && done == 0) launch_scatter<false, true>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, *tag);
         else launch_scatter<false, false>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, Tag{});
         hipError_t e = hipGetLastError();

@@ -4,7 +4,7 @@
 the builder's per-kernel time table."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get('MAGNET_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges
 n, e = 10_000_000, 200_000_000
 src, dst = powerlaw_edges(n, e, 43, device='cuda')

@@ -5,8 +5,8 @@ under profiles/:  <tag>_kernel_stats.csv (per-kernel time of the bench run), <ta
 per SpMM launch, which bench.py reports as roofline.traffic).
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950
-FETCH_SIZE reports half the bytes of 16-byte-per-lane coalesced reads (checked here on the
-builder's make_records kernel, whose traffic is known exactly: per launch 8 bytes read and 8 written per edge).
+FETCH_SIZE reports half the bytes of 16-byte-per-lane coalesced reads (checked here on two kernels whose
+traffic is known exactly: the read-only probe stream_read_kernel and the edge generator powerlaw_kernel).
 spmm_traffic.json records a hash of the SpMM kernel source; bench.py refuses the file when the source has changed since.
 """
 import csv
@@ -41,15 +41,12 @@ per = {}
 for kind in ('fetch', 'write'):
     path = newest(os.path.join(src, kind, '*', '*_counter_collection.csv'))
     recs = list(csv.DictReader(open(path)))
-    # only the headline workload: the bench's secondary epoch measurement builds a second graph
-    builds = sorted(int(r['Dispatch_Id']) for r in recs if 'make_records' in r['Kernel_Name'])
-    cutoff = builds[2] if len(builds) > 2 else float('inf')      # two launches (forward, backward records) per build
+    # the counter passes run bench.py with --no-epoch: every launch belongs to the headline workload
     for r in recs:
-        if int(r['Dispatch_Id']) >= cutoff:
-            continue
         n = r['Kernel_Name']
         key = ('cspmm' if 'cspmm_vec4<' in n else 'cspmm_chunks' if 'cspmm_vec4_chunks' in n else 'cspmm_combine' if 'cspmm_vec4_combine' in n
-               else 'make_records' if 'make_records' in n else 'gemm' if n.startswith('Cijk_') else None)
+               else 'powerlaw' if 'powerlaw_kernel' in n else 'stream_read' if 'stream_read_kernel' in n
+               else 'gemm' if n.startswith('Cijk_') else None)
         if key:
             per.setdefault((key, kind), []).append(
                 (float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
@@ -63,8 +60,10 @@ with open(os.path.join(dst, tag + '_hbm_counters.csv'), 'w', newline='') as f:
 mean = lambda xs: sum(xs) / len(xs)
 fetch = mean([v for v, _ in per[('cspmm', 'fetch')]]) * 1024 * 2
 write = mean([v for v, _ in per[('cspmm', 'write')]]) * 1024
-cal_f = mean([v for v, _ in per[('make_records', 'fetch')]]) * 1024 * 2
-cal_w = mean([v for v, _ in per[('make_records', 'write')]]) * 1024
+# kernels whose traffic is known exactly: the read-only probe of bench.py's ceiling measurement (8 GiB read per launch) and
+# the edge generator (8 bytes written per edge, 50M edges per launch, nothing read)
+cal_f = mean([v for v, _ in per[('stream_read', 'fetch')]]) * 1024 * 2
+cal_w = mean([v for v, _ in per[('powerlaw', 'write')]]) * 1024
 for extra in ('cspmm_chunks', 'cspmm_combine'):       # the hub-row kernels belong to the same SpMM order
     if (extra, 'fetch') in per:
         fetch += mean([v for v, _ in per[(extra, 'fetch')]]) * 1024 * 2
@@ -75,8 +74,9 @@ m = re.search(r'N=(\d+) E=(\d+).*?, (\d+) complex features', bench['config']['wo
 out = {'nodes': int(m.group(1)), 'edges': int(m.group(2)), 'features': int(m.group(3)), 'nnz': nnz,
        'hbm_bytes_per_launch': fetch + write, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
        'algorithmic_bytes_per_launch': bench['roofline']['algorithmic_bytes_per_launch'],
-       'calibration': {'kernel': 'make_records (one launch reads two int32 per edge and writes one 8-byte key per edge)',
-                       'expected_read_bytes': int(m.group(2)) * 8, 'expected_write_bytes': int(m.group(2)) * 8,
+       'calibration': {'kernels': 'stream_read_kernel (reads 8 GiB per launch, writes nothing) for FETCH_SIZE; powerlaw_kernel '
+                                  '(writes 8 bytes per edge, 50M edges per launch) for WRITE_SIZE',
+                       'expected_read_bytes': 8 << 30, 'expected_write_bytes': 50_000_000 * 8,
                        'measured_read_corrected': cal_f, 'measured_write': cal_w},
        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s' % tag,
        'traffic_kind': 'L2 <-> fabric requests (TCC_EA): Infinity Cache (MALL) hits are inside this figure',
