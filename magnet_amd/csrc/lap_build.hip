@@ -198,21 +198,66 @@ struct WaveRuns {
     bool has_next;
 };
 
-// k / in = the lane's record and whether p < m; every lane of the wave calls this
-__device__ inline WaveRuns wave_runs(const uint64_t* __restrict__ keys, int64_t m, int64_t p, int lane, uint64_t k, bool in,
-                                     bool& head) {
+// 64-record groups a wavefront of segments / emit_entries takes: their loads are issued together, so that four times
+// the bytes are in flight per wave (one group per wave left both kernels waiting on memory latency, not bandwidth)
+constexpr int kGroups = 4;
+
+// k / in = the lane's record and whether p < m; every lane of the wave calls this.  `before` = the key of the record
+// in front of the group (used by lane 0; any value when p - lane == 0), `next_key` / `has_next` = the record after it.
+__device__ inline WaveRuns wave_runs(int64_t p, int lane, uint64_t k, bool in, uint64_t before, uint64_t next_key,
+                                     bool has_next, bool& head) {
     WaveRuns r;
-    const int64_t after = p - lane + 64;
-    r.has_next = after < m;
-    r.next_key = r.has_next ? keys[after] : 0ull;
+    r.has_next = has_next;
+    r.next_key = next_key;
     const uint32_t plo = __shfl_up(uint32_t(k), 1, 64), phi = __shfl_up(uint32_t(k >> 32), 1, 64);
     uint64_t prev = (uint64_t(phi) << 32) | plo;
-    if (lane == 0 && p > 0 && in) prev = keys[p - 1];
+    if (lane == 0) prev = before;
     head = in && (p == 0 || (prev >> 1) != (k >> 1));
     r.in_mask = __ballot(in);
     r.head_mask = __ballot(head);
     r.dir_mask = __ballot(in && (k & 1ull));
     return r;
+}
+
+// the records of a wavefront's kGroups groups, and the keys around them, loaded in one go
+struct WaveRecords {
+    uint64_t k[kGroups];
+    float w[kGroups];
+    bool in[kGroups];
+    uint64_t before, after;
+    bool has_after;
+};
+
+__device__ inline WaveRecords load_records(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted, int64_t m,
+                                           int64_t base, int lane) {
+    WaveRecords R;
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const int64_t p = base + u * 64 + lane;
+        R.in[u] = p < m;
+        R.k[u] = R.in[u] ? keys[p] : 0ull;
+        R.w[u] = (R.in[u] && w_sorted) ? w_sorted[p] : 1.0f;
+    }
+    R.before = base > 0 ? keys[base - 1] : 0ull;
+    const int64_t after = base + 64 * kGroups;
+    R.has_after = after < m;
+    R.after = R.has_after ? keys[after] : 0ull;
+    return R;
+}
+
+__device__ inline uint64_t lane_value(uint64_t v, int src_lane) {      // v of lane src_lane (0 or 63), wave-uniform
+    const uint32_t lo = src_lane == 0 ? __builtin_amdgcn_readfirstlane(uint32_t(v)) : __builtin_amdgcn_readlane(uint32_t(v), 63);
+    const uint32_t hi = src_lane == 0 ? __builtin_amdgcn_readfirstlane(uint32_t(v >> 32)) : __builtin_amdgcn_readlane(uint32_t(v >> 32), 63);
+    return (uint64_t(hi) << 32) | lo;
+}
+
+// group u of a wavefront's records: its run structure
+__device__ inline WaveRuns group_runs(const WaveRecords& R, int u, int64_t m, int64_t base, int lane, bool& head) {
+    const uint64_t before = u == 0 ? R.before : lane_value(R.k[u > 0 ? u - 1 : 0], 63);
+    const bool last = u + 1 == kGroups;
+    const uint64_t next_key = last ? R.after : lane_value(R.k[last ? u : u + 1], 0);
+    const bool has_next = last ? R.has_after : (base + (u + 1) * 64 < m);
+    return wave_runs(base + u * 64 + lane, lane, R.k[u], R.in[u], before, next_key, has_next, head);
 }
 
 // Sums of the run that starts at this lane's record (meaningful for run heads; every lane of the wave calls this, `want`
@@ -277,28 +322,31 @@ __device__ inline bool run_sums(const uint64_t* __restrict__ keys, const float* 
 __global__ void __launch_bounds__(kBlock) segments(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
                                                    int64_t m, uint64_t* __restrict__ bits, uint32_t* __restrict__ long_list,
                                                    Header* hdr) {
-    const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    if (p - lane >= m) return;                          // the whole wavefront lies past the records
-    const bool in = p < m;
-    const uint64_t k = in ? keys[p] : 0ull;
-    const float w = (in && w_sorted) ? w_sorted[p] : 1.0f;
-    bool head;
-    const WaveRuns runs = wave_runs(keys, m, p, lane, k, in, head);
-    float fwd, bwd;
-    const bool is_short = run_sums(keys, w_sorted, m, p, lane, k, w, runs, head, fwd, bwd);
-    bool keep = false;
-    if (head) {
-        if (is_short) {
-            float sv, dv;
-            segment_values(fwd, bwd, sv, dv);
-            keep = segment_kept(sv, dv) != 0;
-        } else {
-            long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag bit set by segments_long
+    const int64_t base = ((int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6) * (64 * kGroups);
+    if (base >= m) return;                              // the whole wavefront lies past the records
+    const WaveRecords R = load_records(keys, w_sorted, m, base, lane);
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const int64_t p = base + u * 64 + lane;
+        if (p - lane >= m) break;                       // wave-uniform
+        bool head;
+        const WaveRuns runs = group_runs(R, u, m, base, lane, head);
+        float fwd, bwd;
+        const bool is_short = run_sums(keys, w_sorted, m, p, lane, R.k[u], R.w[u], runs, head, fwd, bwd);
+        bool keep = false;
+        if (head) {
+            if (is_short) {
+                float sv, dv;
+                segment_values(fwd, bwd, sv, dv);
+                keep = segment_kept(sv, dv) != 0;
+            } else {
+                long_list[atomicAdd(&hdr->n_long, 1)] = uint32_t(p);     // flag bit set by segments_long
+            }
         }
+        const uint64_t word = __ballot(keep);
+        if (lane == 0) bits[p >> 6] = word;
     }
-    const uint64_t word = __ballot(keep);
-    if (lane == 0) bits[p >> 6] = word;
 }
 
 // One wavefront per long run, 64 records per step: the lanes load the step's records side by side (coalesced),
@@ -388,7 +436,7 @@ __global__ void __launch_bounds__(kBlock) write_row_ptr(const int32_t* __restric
 }
 
 // ---------------------------------------------------------------------------
-// 6. emission: a wavefront takes the 64 records of one flag word
+// 6. emission: a wavefront takes kGroups flag words (64 records each)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restrict__ keys, const float* __restrict__ w_sorted,
                                                        const uint64_t* __restrict__ bits,
@@ -398,39 +446,51 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
                                                        int64_t m, int cb, int32_t row_lo, float two_pi_q, float scale, int diag,
                                                        int64_t nnz, int tagged, int32_t* __restrict__ col_idx,
                                                        float2* __restrict__ val) {
-    const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    if (p - lane >= m) return;
-    const uint64_t word = bits[p >> 6];
-    if (word == 0ull) return;                           // no kept entry among these 64 records
-    const bool in = p < m;
-    const uint64_t k = in ? keys[p] : 0ull;
-    const float w = (in && w_sorted) ? w_sorted[p] : 1.0f;
-    const bool kept = (word >> lane) & 1ull;            // kept entries are run heads
-    bool head;
-    const WaveRuns runs = wave_runs(keys, m, p, lane, k, in, head);
-    float fwd, bwd, sv, dv;
-    const bool is_short = run_sums(keys, w_sorted, m, p, lane, k, w, runs, kept, fwd, bwd);
-    if (!kept) return;
-    if (is_short) segment_values(fwd, bwd, sv, dv);
-    else { sv = seg_s[p]; dv = seg_d[p]; }              // a long run: summed by segments_long
+    const int64_t base = ((int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6) * (64 * kGroups);
+    if (base >= m) return;
+    const WaveRecords R = load_records(keys, w_sorted, m, base, lane);
+    uint64_t words[kGroups];
+    uint32_t first_slot[kGroups];
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const bool any = base + u * 64 < m;
+        words[u] = any ? bits[(base >> 6) + u] : 0ull;
+        first_slot[u] = any ? word_pos[(base >> 6) + u] : 0u;
+    }
     const uint64_t node_mask = (1ull << cb) - 1ull;
-    int32_t r = int32_t((k >> (cb + 1)) & node_mask);
-    int32_t c = int32_t((k >> 1) & node_mask);
-    int64_t idx = int64_t(word_pos[p >> 6]) + int64_t(__popcll(word & ((1ull << lane) - 1ull)));
-    if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
-    if (idx >= nnz) return;                            // caller's arrays are shorter than the count phase reported
-    float dc;
-    const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
-    if (tag < kTagCap) dc = tag_table[tag];            // the column's record count travelled in the key
-    else dc = dinv[c];
-    float a = (dinv[r] * sv) * dc;                     // (D A_s) D, hermitian.py:154
-    float theta = two_pi_q * dv;                       // fp32 product, hermitian.py:157
-    float sn, cs;
-    sincosf(theta, &sn, &cs);                          // full-range accurate sincos, hermitian.py:158
-    float re = -(cs * a), im = -(sn * a);              // I - Theta.*A_s off the diagonal, hermitian.py:164
-    col_idx[idx] = c;
-    val[idx] = make_float2(re * scale, im * scale);    // (2/lmax) L - I, hermitian.py:167
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const uint64_t word = words[u];
+        if (word == 0ull) continue;                     // no kept entry among these 64 records (wave-uniform)
+        const int64_t p = base + u * 64 + lane;
+        const uint64_t k = R.k[u];
+        const bool kept = (word >> lane) & 1ull;        // kept entries are run heads
+        bool head;
+        const WaveRuns runs = group_runs(R, u, m, base, lane, head);
+        float fwd, bwd, sv, dv;
+        const bool is_short = run_sums(keys, w_sorted, m, p, lane, k, R.w[u], runs, kept, fwd, bwd);
+        if (!kept) continue;
+        if (is_short) segment_values(fwd, bwd, sv, dv);
+        else { sv = seg_s[p]; dv = seg_d[p]; }          // a long run: summed by segments_long
+        int32_t r = int32_t((k >> (cb + 1)) & node_mask);
+        int32_t c = int32_t((k >> 1) & node_mask);
+        int64_t idx = int64_t(first_slot[u]) +
+                      int64_t(__builtin_amdgcn_mbcnt_hi(uint32_t(word >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(word), 0u)));
+        if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
+        if (idx >= nnz) continue;                       // caller's arrays are shorter than the count phase reported
+        float dc;
+        const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
+        if (tag < kTagCap) dc = tag_table[tag];         // the column's record count travelled in the key
+        else dc = dinv[c];
+        float a = (dinv[r] * sv) * dc;                  // (D A_s) D, hermitian.py:154
+        float theta = two_pi_q * dv;                    // fp32 product, hermitian.py:157
+        float sn, cs;
+        sincosf(theta, &sn, &cs);                       // full-range accurate sincos, hermitian.py:158
+        float re = -(cs * a), im = -(sn * a);           // I - Theta.*A_s off the diagonal, hermitian.py:164
+        col_idx[idx] = c;
+        val[idx] = make_float2(re * scale, im * scale); // (2/lmax) L - I, hermitian.py:167
+    }
 }
 
 // diagonal (2/lmax - 1) of every row of the block; its slot follows the row's kept entries with col < r
@@ -537,7 +597,7 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int
     float* seg_s = reinterpret_cast<float*>(W.keys0);           // keys0 is free after the sort
     float* seg_d = seg_s + L.m_pad;
     if (L.m > 0) {
-        segments<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, W.bits, W.long_list, W.hdr);
+        segments<<<grid_for((L.m + kGroups - 1) / kGroups), kBlock, 0, stream>>>(W.keys1, W.w1, L.m, W.bits, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments");
         segments_long<<<1024, kBlock, 0, stream>>>(W.keys1, W.w1, L.m, seg_s, seg_d, W.bits, W.long_list, W.hdr);
         MH_LAUNCH_CHECK("segments_long");
@@ -579,7 +639,7 @@ int fill_sorted(const Layout& L, const Work& W, bool tagged, int32_t row_lo, int
             tag_table_kernel<<<grid_for(kTagCap), kBlock, 0, stream>>>(W.tag_table);
             MH_LAUNCH_CHECK("tag_table");
         }
-        emit_entries<<<grid_for(L.m), kBlock, 0, stream>>>(W.keys1, W.w1, W.bits, W.word_pos, seg_s, seg_d, dinv, W.tag_table, L.m, L.cb, row_lo,
+        emit_entries<<<grid_for((L.m + kGroups - 1) / kGroups), kBlock, 0, stream>>>(W.keys1, W.w1, W.bits, W.word_pos, seg_s, seg_d, dinv, W.tag_table, L.m, L.cb, row_lo,
                                                            two_pi_q, scale, diag, nnz, tagged ? 1 : 0, col_idx,
                                                            reinterpret_cast<float2*>(val));
         MH_LAUNCH_CHECK("emit_entries");
