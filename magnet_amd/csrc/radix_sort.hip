@@ -4,9 +4,10 @@
 // Per pass, three steps over tiles of 8192 keys (512 threads = 8 wavefronts x 16 rounds x 64 lanes):
 //   1. tile_histogram   256-bin digit histogram of every tile (LDS atomics), stored tile-major so
 //                       that a tile's 256 counters are one contiguous 1 KiB line;
-//   2. scan_*           column-wise exclusive scan of the [tiles][256] matrix in digit-major order:
-//                       chunk sums (256 tiles per chunk), one workgroup scanning the chunk sums and
-//                       the digit totals, then every chunk turning its counters into global offsets;
+//   2. scan_apply       column-wise exclusive scan of the [tiles][256] matrix in digit-major order: the histogram
+//                       kernel also adds each tile's counts to its chunk's totals (256 tiles per chunk); one workgroup
+//                       per chunk sums the totals before it, scans the 256 digit totals and turns its tiles'
+//                       counters into global offsets;
 //   3. scatter          each wavefront ranks its 1024 keys round by round with ballot "match" masks
 //                       (8 ballots give the lanes holding the same digit; the population count below
 //                       a lane is its rank), waves are offset against each other per digit, the tile is
@@ -63,7 +64,8 @@ __device__ inline uint64_t key_at(const uint64_t* __restrict__ keys, const Recor
 
 template <int GEN>
 __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                           uint32_t mask, uint32_t* __restrict__ hist, const RecordSource gen) {
+                                                           uint32_t mask, uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ chunk_sum, const RecordSource gen) {
     __shared__ uint32_t bins[kBins];
     if (threadIdx.x < kBins) bins[threadIdx.x] = 0;
     __syncthreads();
@@ -74,53 +76,41 @@ __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __res
         if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kBins) hist[int64_t(blockIdx.x) * kBins + threadIdx.x] = bins[threadIdx.x];
-}
-
-// chunk_sum[c][d] = sum over the chunk's tiles of hist[t][d]
-__global__ void __launch_bounds__(kBins) scan_chunk_sums(const uint32_t* __restrict__ hist, int64_t n_tiles,
-                                                         uint32_t* __restrict__ chunk_sum) {
-    const int d = threadIdx.x;
-    const int64_t t0 = int64_t(blockIdx.x) * kChunk;
-    const int64_t t1 = t0 + kChunk < n_tiles ? t0 + kChunk : n_tiles;
-    uint32_t s = 0;
-    for (int64_t t = t0; t < t1; ++t) s += hist[t * kBins + d];
-    chunk_sum[int64_t(blockIdx.x) * kBins + d] = s;
-}
-
-// one workgroup: chunk_sum[c][d] -> global offset of (digit d, first tile of chunk c)
-__global__ void __launch_bounds__(kBins) scan_chunks(uint32_t* __restrict__ chunk_sum, int64_t n_chunks) {
-    __shared__ uint32_t total[kBins];
-    const int d = threadIdx.x;
-    uint32_t run = 0;
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        uint32_t v = chunk_sum[c * kBins + d];
-        chunk_sum[c * kBins + d] = run;
-        run += v;
+    if (threadIdx.x < kBins) {
+        const uint32_t c = bins[threadIdx.x];
+        hist[int64_t(blockIdx.x) * kBins + threadIdx.x] = c;
+        // per digit, the sum over the chunk's tiles (integer adds: the order does not matter)
+        if (c) atomicAdd(&chunk_sum[int64_t(blockIdx.x / kChunk) * kBins + threadIdx.x], c);
     }
-    total[d] = run;
-    __syncthreads();
-    // exclusive scan of the 256 digit totals (Hillis-Steele in LDS)
-    uint32_t v = total[d];
-    uint32_t inc = v;
-    for (int off = 1; off < kBins; off <<= 1) {
-        uint32_t t = d >= off ? total[d - off] : 0u;
-        __syncthreads();
-        inc = total[d] + t;
-        total[d] = inc;
-        __syncthreads();
-    }
-    const uint32_t digit_base = inc - v;
-    for (int64_t c = 0; c < n_chunks; ++c) chunk_sum[c * kBins + d] += digit_base;
 }
 
-// hist[t][d] -> global offset of (digit d, tile t)
+// hist[t][d] (counts) -> global offset of (digit d, tile t), digit-major: all of digit 0, then digit 1, ...  One workgroup
+// per chunk of 256 tiles, one thread per digit.  chunk_sum[c][d] holds the chunks' totals (tile_histogram): every workgroup
+// adds up the chunks before its own and all chunks (the digit's total), scans the 256 totals, and walks its tiles.
 __global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist, int64_t n_tiles,
-                                                    const uint32_t* __restrict__ chunk_off) {
-    const int d = threadIdx.x;
+                                                    const uint32_t* __restrict__ chunk_sum, int64_t n_chunks) {
+    __shared__ uint32_t wave_total[kBins / 64];
+    const int d = threadIdx.x, lane = d & 63, w = d >> 6;
+    uint32_t before = 0, total = 0;
+#pragma unroll 8
+    for (int64_t c = 0; c < n_chunks; ++c) {            // independent loads: issued in batches
+        const uint32_t v = chunk_sum[c * kBins + d];
+        before += c < int64_t(blockIdx.x) ? v : 0u;
+        total += v;
+    }
+    uint32_t inc = total;                               // exclusive scan of the digit totals
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_total[w] = inc;
+    __syncthreads();
+    uint32_t digit_base = inc - total;
+    for (int ww = 0; ww < kBins / 64; ++ww) digit_base += ww < w ? wave_total[ww] : 0u;
     const int64_t t0 = int64_t(blockIdx.x) * kChunk;
     const int64_t t1 = t0 + kChunk < n_tiles ? t0 + kChunk : n_tiles;
-    uint32_t run = chunk_off[int64_t(blockIdx.x) * kBins + d];
+    uint32_t run = digit_base + before;
     for (int64_t t = t0; t < t1; ++t) {
         uint32_t v = hist[t * kBins + d];
         hist[t * kBins + d] = run;
@@ -388,11 +378,13 @@ inline size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
 
+constexpr int kMaxPasses = 8;              // 64 key bits
+
 size_t workspace_bytes(int64_t n) {
     int64_t tiles = (n + kTile - 1) / kTile;
     if (tiles < 1) tiles = 1;
     int64_t chunks = (tiles + kChunk - 1) / kChunk;
-    return align_up(size_t(tiles) * kBins * 4) + align_up(size_t(chunks) * kBins * 4);
+    return align_up(size_t(tiles) * kBins * 4) + align_up(size_t(chunks) * kBins * 4 * kMaxPasses);
 }
 
 hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int first_bit, int bits, void* workspace,
@@ -403,8 +395,13 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
     const int64_t tiles = (n + kTile - 1) / kTile;
     const int64_t chunks = (tiles + kChunk - 1) / kChunk;
     uint32_t* hist = static_cast<uint32_t*>(workspace);
-    uint32_t* chunk = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align_up(size_t(tiles) * kBins * 4));
+    uint32_t* chunk_all = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align_up(size_t(tiles) * kBins * 4));
     const bool pairs = va != nullptr;
+    if (passes_for(bits) > kMaxPasses) return hipErrorInvalidValue;
+    // the chunk totals of every pass are accumulated by that pass's histogram: one clear for all of them
+    hipError_t e0 = hipMemsetAsync(chunk_all, 0, size_t(chunks) * kBins * 4 * passes_for(bits), stream);
+    if (e0 != hipSuccess) return e0;
+    int pass = 0;
     // equal digit widths over the passes (42 key bits -> 6 passes of 7 bits): fewer bins per pass
     // means longer runs of equal digit per tile, i.e. longer contiguous writes
     const int width = (bits + passes_for(bits) - 1) / passes_for(bits);
@@ -414,12 +411,11 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
         const uint32_t mask = (1u << nb) - 1u;
         const bool from_source = gen != nullptr && done == 0;
         if (from_source && shift + nb > 32) return hipErrorInvalidValue;
-        if (!from_source) tile_histogram<0><<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist, RecordSource{});
-        else if (gen->idx64) tile_histogram<2><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, *gen);
-        else tile_histogram<1><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, *gen);
-        scan_chunk_sums<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
-        scan_chunks<<<1, kBins, 0, stream>>>(chunk, chunks);
-        scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk);
+        uint32_t* chunk = chunk_all + size_t(pass++) * size_t(chunks) * kBins;
+        if (!from_source) tile_histogram<0><<<unsigned(tiles), kThreads, 0, stream>>>(a, n, shift, mask, hist, chunk, RecordSource{});
+        else if (gen->idx64) tile_histogram<2><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, chunk, *gen);
+        else tile_histogram<1><<<unsigned(tiles), kThreads, 0, stream>>>(nullptr, n, shift, mask, hist, chunk, *gen);
+        scan_apply<<<unsigned(chunks), kBins, 0, stream>>>(hist, tiles, chunk, chunks);
         if (from_source) {
             if (pairs) {
                 if (gen->idx64) launch_scatter_gen<true, 2>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
