@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r03/collect
+O=gpurun_out/run/collect
 mkdir -p $O
 timeout -k 10 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 echo "bench done"
