@@ -22,7 +22,7 @@ import torch.optim as optim
 
 from . import data as D
 from .layer.sparse_magnet import ChebNet
-from .train import node_epoch, GraphedEpoch
+from .train import node_epoch, GraphedEpoch, NodeTargets
 from .utils.preprocess import geometric_dataset_sparse
 from .utils.save_settings import write_log
 
@@ -184,7 +184,10 @@ def main(args):
         as_index = lambda m: torch.from_numpy(m).to(device).nonzero().squeeze(1) if m.dtype == np.bool_ \
             else torch.from_numpy(m).to(device).long()
         train_index, val_index, test_index = (as_index(m[:, split]) for m in (train_mask, val_mask, test_mask))
-        body = lambda: node_epoch(model, opt, X_real, X_img, label, train_index, val_index, criterion)
+        # the split's labels with the other nodes ignored: loss and accuracy of the reference's
+        # criterion(preds[:, :, index], label[:, index]) without the per-epoch gather and index-put
+        train_targets, val_targets = NodeTargets(label, train_index), NodeTargets(label, val_index)
+        body = lambda: node_epoch(model, opt, X_real, X_img, label, train_targets, val_targets, criterion)
         if args.hip_graph:
             # the capture's warm-up epochs are real optimizer steps: rewind parameters and Adam state in place
             start = [p.detach().clone() for p in model.parameters()]

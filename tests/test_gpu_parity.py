@@ -1686,3 +1686,23 @@ def test_node_targets_give_the_reference_loss_without_gathering():
         assert_close(np.array(stats), np.array(res[0][0]), rel=1e-6, what='loss / accuracy')
         for a, b in zip(grads, res[0][1]):
             assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize('e', [32, 128, 512, 4096, 8192, 8193, 12288])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_builder_at_tile_boundaries(e, weighted):
+    """Record counts that land exactly on (or one past) the builder's internal granularities — a wavefront's 64 records,
+    a workgroup's 256 x 4, a sort tile's 8192 — with duplicate-heavy edges so that runs straddle those borders."""
+    _, lap, H, _, O = _mods()
+    rng = np.random.default_rng(e + int(weighted))
+    n = 37
+    row = rng.integers(0, n, e); col = rng.integers(0, n, e)
+    w = rng.integers(1, 6, e).astype(np.float32) if weighted else None
+    L = H.hermitian_decomp_sparse(row, col, n, 0.2, edge_weight=w)
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.2, edge_weight=w)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what='e=%d' % e)
+    # one directed pair listed e times: a single long run over every border, handed to a whole wavefront
+    one = np.zeros(e, np.int64)
+    L = H.hermitian_decomp_sparse(one, one + 3, n, 0.2, edge_weight=w)
+    Lo = O.hermitian_decomp_sparse(one, one + 3, n, 0.2, edge_weight=w)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what='one pair, e=%d' % e)
