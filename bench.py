@@ -280,35 +280,65 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
     return out
 
 
+def time_variant(conv, mode, K, nnz_total, dev, multi, steps, cap=0):
+    """`steps` steps of the row-partitioned conv in one arrangement of its exchange: wall time per step (max over ranks),
+    the compute stream's wait for each order's exchange (HIP events around the wait, max over ranks), the host time
+    spent issuing one exchange."""
+    import torch.distributed as dist
+    from magnet_amd import dist as D
+    part = conv.part
+    part.set_mode(mode, int_grid_cap=cap)
+    conv.step()
+    part.wait_events, part.issue_seconds = [], []
+    t = timed_steps(conv.step, steps, dev, multi)
+    ev, issue = part.wait_events, part.issue_seconds
+    part.wait_events = part.issue_seconds = None
+    waits = [a.elapsed_time(b) for a, b in ev]
+    # every rank takes part in the reduction whatever it recorded (a rank without halo records no wait)
+    mine = [sum(waits[i::K]) / steps for i in range(K)] if (len(waits) == K * steps and K > 0) else [0.0] * K
+    w = torch.tensor(mine + [float(len(waits))], device=dev, dtype=torch.float64)
+    if dist.is_initialized():
+        D.all_reduce(w, op=dist.ReduceOp.MAX)
+    per_order = w[:K].tolist() if w[K].item() > 0 else None
+    res = {'ms_per_step': t / steps * 1e3, 'edges_per_s': nnz_total * K / (t / steps),
+           'exposed_wait_ms_per_order': per_order,
+           'exposed_wait_ms_per_step': None if per_order is None else sum(per_order),
+           'host_issue_ms_per_exchange_rank0': (sum(issue) / len(issue) * 1e3) if issue else None}
+    part._gathered.clear()
+    return res
+
+
+def extension_variant(conv, K, nnz_total, dev, multi, steps=3):
+    """The same conv with every exchange posted by the library itself (mh_exchange_*: packing launches and the grouped
+    RCCL send/receive from native code on the library's own communicator and stream), timed like the other
+    arrangements, and its output compared with the torch.distributed arrangement's on the same input."""
+    import torch.distributed as dist
+    from magnet_amd import dist as D
+    part = conv.part
+    part.set_mode('overlap')
+    want = conv.step().clone()
+    res = time_variant(conv, part.NATIVE_MODE, K, nnz_total, dev, multi, steps)
+    got = conv.step()
+    diff = torch.tensor([float((got - want).abs().max())], device=dev, dtype=torch.float64)
+    if dist.is_initialized():
+        D.all_reduce(diff, op=dist.ReduceOp.MAX)
+    res['max_abs_difference_from_overlap'] = diff.item()
+    res['note'] = 'exchange posted by the library (mh_exchange_begin / mh_exchange_end) instead of torch.distributed'
+    part.set_mode('overlap')
+    part.close()
+    return res
+
+
 def row_variants(conv, K, nnz_total, dev, multi, steps=3):
     """The row-partitioned conv timed in every arrangement of its halo exchange (magnet_amd.dist.RowPartition.set_mode),
     `steps` steps each, and with the transfers switched off.  Per arrangement: wall time per step (max over ranks) and
     the time the compute stream sat waiting for each order's exchange (HIP events around the wait, max over ranks) —
     what the overlap did not hide.  Also the host time spent issuing one exchange."""
-    import torch.distributed as dist
-    from magnet_amd import dist as D
     part = conv.part
     cap = 6 * torch.cuda.get_device_properties(dev).multi_processor_count
     out = {}
     for mode in part.MODES:
-        part.set_mode(mode, int_grid_cap=cap)
-        conv.step()
-        part.wait_events, part.issue_seconds = [], []
-        t = timed_steps(conv.step, steps, dev, multi)
-        ev, issue = part.wait_events, part.issue_seconds
-        part.wait_events = part.issue_seconds = None
-        waits = [a.elapsed_time(b) for a, b in ev]
-        # every rank takes part in the reduction whatever it recorded (a rank without halo records no wait)
-        mine = [sum(waits[i::K]) / steps for i in range(K)] if (len(waits) == K * steps and K > 0) else [0.0] * K
-        w = torch.tensor(mine + [float(len(waits))], device=dev, dtype=torch.float64)
-        if dist.is_initialized():
-            D.all_reduce(w, op=dist.ReduceOp.MAX)
-        per_order = w[:K].tolist() if w[K].item() > 0 else None
-        out[mode] = {'ms_per_step': t / steps * 1e3, 'edges_per_s': nnz_total * K / (t / steps),
-                     'exposed_wait_ms_per_order': per_order,
-                     'exposed_wait_ms_per_step': None if per_order is None else sum(per_order),
-                     'host_issue_ms_per_exchange_rank0': (sum(issue) / len(issue) * 1e3) if issue else None}
-        part._gathered.clear()
+        out[mode] = time_variant(conv, mode, K, nnz_total, dev, multi, steps, cap)
     out['overlap_capped']['own_column_product_workgroups'] = cap
     out['all_gather']['rows_received_per_rank_per_order'] = getattr(part, 'max_rows', 0) * (part.world - 1)
     out['overlap']['rows_received_per_rank_per_order_rank0'] = part.n_halo
@@ -322,7 +352,8 @@ def row_variants(conv, K, nnz_total, dev, multi, steps=3):
     out['how_to_read'] = ('overlap vs compute_only: cost of the exchange after overlap; overlap vs sequential: what the overlap '
                           'buys; overlap_capped vs overlap: whether the copy kernels were starved of compute units; all_gather vs '
                           'overlap: one RCCL collective against a batch of point-to-point transfers; exposed_wait: per order, the '
-                          'part of the exchange that the own-column product did not cover')
+                          'part of the exchange that the own-column product did not cover; extension (added after the epochs, one process per '
+                          'GPU over RCCL only): overlap with the exchange posted by the library instead of torch.distributed')
     return out
 
 
@@ -606,7 +637,16 @@ def main():
     # The headline above is complete.  The secondary GPU measurements that follow must not be able to lose it:
     # if they have not finished after 6 minutes (a collective that never completes, a hung kernel), rank 0
     # prints the line without them, says why on stderr, and every rank ends with a non-zero status.
+    stage = ['secondary']
+
     def give_up():
+        if stage[0] == 'extension':
+            if out is not None and isinstance(dist_info.get('row_variants'), dict):
+                dist_info['row_variants']['extension'] = {'error': 'did not finish within 150 s'}
+            sys.stderr.write('bench.py: the library-posted exchange did not finish within 150 s; line printed without it\n')
+            sys.stderr.flush()
+            emit()
+            os._exit(0)
         if out is not None:
             out['epoch'] = {'error': 'secondary measurements did not finish within 360 s'}
         sys.stderr.write('bench.py: secondary measurements did not finish within 360 s; headline printed, exiting with status 3\n')
@@ -615,6 +655,7 @@ def main():
         os._exit(3)
 
     import threading
+    rconv = None
     watchdog = threading.Timer(360.0, give_up)
     watchdog.daemon = True
     watchdog.start()
@@ -640,8 +681,8 @@ def main():
                                         'exposed_comm_ms_per_step': ov['ms_per_step'] - variants['compute_only_ms_per_step'],
                                         'note': 'same conv, rows of L and X partitioned, compact [own | halo] buffers, K halo '
                                                 'exchanges per conv (the overlap variant of multi_gpu.row_variants)'}
-            del rconv
         except Exception as ex:
+            rconv = None
             if out is not None:
                 dist_info['row_variants'] = {'error': repr(ex)[:300]}
         step = None
@@ -665,9 +706,26 @@ def main():
             epoch['layouts'] = results
         if out is not None:
             out['epoch'] = epoch
+    # Last, because it is the one leg no machine of the build could run with RCCL between several GPUs: the row-partitioned
+    # conv with its exchanges posted by the library.  Everything above is already in `out`; a failure or a hang here
+    # costs this leg only (its own time limit; the line is printed with what is there and the status stays 0).
+    watchdog.cancel()
+    if multi and rconv is not None and (backend == 'nccl' or os.environ.get('MAGNET_RCCL_LIBRARY')):
+        stage[0] = 'extension'
+        watchdog = threading.Timer(150.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        note(rank, 'row partition with the exchange posted by the library')
+        try:
+            res = extension_variant(rconv, K, nnz_total, dev, multi)
+        except Exception as ex:
+            res = {'error': repr(ex)[:300]}
+        if out is not None and isinstance(dist_info.get('row_variants'), dict):
+            dist_info['row_variants']['extension'] = res
+        watchdog.cancel()
+    rconv = None
     if multi:
         dist.destroy_process_group()
-    watchdog.cancel()                                   # the GPU work is over; the CPU baseline has its own bound
     if rank == 0 and not args.no_cpu_baseline:          # at every N: rank 0's host cores, after the ranks have parted
         args.full_nnz = nnz_total
         note(rank, 'CPU baseline on a sample (host cores)')

@@ -33,6 +33,7 @@ extern "C" {
 #define MH_ERR_INDEX (-3)      /* an edge endpoint is outside [0, n_nodes) */
 #define MH_ERR_WORKSPACE (-4)  /* workspace too small */
 #define MH_ERR_RANGE (-5)      /* problem too large for int32 CSR indices */
+#define MH_ERR_COMM (-6)       /* the communication library (RCCL) is missing or returned an error */
 
 int mh_version(void);
 const char* mh_last_error(void);
@@ -267,6 +268,57 @@ int mh_relu_bwd(float* G, int64_t ld, int64_t im, const uint8_t* mask,
  * side-by-side block [N][2][K+1][F] that the backward recursion then continues from (no copy of G first). */
 int mh_relu_bwd_to(const float* G, int64_t ld, int64_t im, const uint8_t* mask,
                    float* out, int64_t ldo, int64_t imo, int64_t n_rows, int32_t F, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Halo exchange of a row-partitioned run, posted from native code over RCCL.  No counterpart in the
+ * reference, which runs on one device (src/sparse_Magnet.py:23-24, src/Edge_sparseMagnet.py:148); it
+ * serves the row partition that mh_lap_block_* and mh_halo_plan_* set up.
+ *
+ * One process per GPU.  An exchange object holds the rank's RCCL communicator, a stream of its own, and
+ * the plan: for every peer p the rows of this rank's block that p gathers (give_rows[p]: DEVICE int32
+ * row numbers inside the block, ascending, no repeats; give_count[p] of them, HOST) and where the rows
+ * that p serves land in this rank's halo (halo rows [recv_ptr[p], recv_ptr[p+1]), HOST prefix array of
+ * world + 1 entries; a peer's give list and this rank's slice for it have the same length by
+ * construction of the halo plan).  The give_rows arrays must stay allocated while the object lives.
+ *
+ * RCCL is loaded at run time (the copy already in the process if there is one; the environment variable
+ * MAGNET_RCCL_LIBRARY names another): a process that never creates an exchange never loads it, and all
+ * other entry points work without it.  Failures return MH_ERR_COMM.
+ *
+ *   mh_exchange_new_id   128 opaque bytes naming a new communicator: made on ONE rank and carried to the
+ *                        others by the caller's own means (a file, MPI, torch.distributed ...).
+ *   mh_exchange_create   COLLECTIVE over the `world` ranks (ncclCommInitRank), on the current device.
+ *   mh_exchange_begin    posts one order's exchange of a row-planar matrix: `own` (n_local rows, row
+ *                        stride ld, part stride im: may be one order of a side-by-side block) is what the
+ *                        peers are served from, `halo` [n_halo][2][F] (contiguous) is where this rank's
+ *                        halo rows arrive.  Peers that take a subset of the rows get a packed copy
+ *                        (mh_gather_rows on `compute_stream`, into a staging area the object grows on
+ *                        demand: hipMalloc on the first call of a width); a peer that takes the whole,
+ *                        contiguous block is sent it in place.  The transfers, one grouped
+ *                        ncclSend/ncclRecv per peer, run on the exchange's stream after everything
+ *                        queued on `compute_stream` so far; the call returns at once, and work queued on
+ *                        `compute_stream` afterwards overlaps them.  `own` and `halo` must not be
+ *                        written / read until mh_exchange_end.
+ *   mh_exchange_end      makes `compute_stream` wait for the exchange begun last (a stream-side wait; the
+ *                        host does not block).  One exchange is in flight per object at a time: a second
+ *                        begin first orders itself after the one before.
+ *   mh_exchange_all_gather   ONE ncclAllGather of `floats_per_rank` floats from every rank into `all`
+ *                        [world * floats_per_rank], with the same stream ordering; completed by
+ *                        mh_exchange_end.
+ *   mh_exchange_destroy  waits for the exchange's stream, destroys communicator, stream and staging.
+ */
+typedef struct mh_exchange mh_exchange;
+int mh_exchange_id_bytes(void);
+int mh_exchange_new_id(void* id, size_t id_bytes);
+int mh_exchange_create(const void* id, size_t id_bytes, int32_t rank, int32_t world,
+                       const int32_t* const* give_rows, const int64_t* give_count,
+                       const int64_t* recv_ptr, int64_t n_local, mh_exchange** out);
+int mh_exchange_begin(mh_exchange* x, const float* own, int64_t ld, int64_t im, float* halo, int32_t F,
+                      void* compute_stream);
+int mh_exchange_end(mh_exchange* x, void* compute_stream);
+int mh_exchange_all_gather(mh_exchange* x, const float* mine, float* all, int64_t floats_per_rank,
+                           void* compute_stream);
+int mh_exchange_destroy(mh_exchange* x);
 
 /* ---------------------------------------------------------------------------
  * Synthetic power-law digraph (bench / scale tests).  Edge e (0-based, global

@@ -91,6 +91,20 @@ def _load():
     lib.mh_cspmm_noalloc_init.argtypes = []
     lib.mh_cspmm_set_grid_cap.restype = C.c_int
     lib.mh_cspmm_set_grid_cap.argtypes = [i32]
+    lib.mh_exchange_id_bytes.restype = C.c_int
+    lib.mh_exchange_id_bytes.argtypes = []
+    lib.mh_exchange_new_id.restype = C.c_int
+    lib.mh_exchange_new_id.argtypes = [vp, sz]
+    lib.mh_exchange_create.restype = C.c_int
+    lib.mh_exchange_create.argtypes = [vp, sz, i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), i64, C.POINTER(vp)]
+    lib.mh_exchange_begin.restype = C.c_int
+    lib.mh_exchange_begin.argtypes = [vp, vp, i64, i64, vp, i32, vp]
+    lib.mh_exchange_end.restype = C.c_int
+    lib.mh_exchange_end.argtypes = [vp, vp]
+    lib.mh_exchange_all_gather.restype = C.c_int
+    lib.mh_exchange_all_gather.argtypes = [vp, vp, vp, i64, vp]
+    lib.mh_exchange_destroy.restype = C.c_int
+    lib.mh_exchange_destroy.argtypes = [vp]
     lib.mh_powerlaw_edges.restype = C.c_int
     lib.mh_powerlaw_edges.argtypes = [i32, i64, u64, i64, vp, vp, vp]
     lib.mh_stream_read.restype = C.c_int
@@ -104,7 +118,8 @@ lib = _load()
 OPS = ['cspmm', 'cspmm_noalloc', 'plan_build', 'cheb_terms_', 'clenshaw', 'lap_build', 'lap_block_count',
        'lap_block_fill', 'pack', 'unpack',
        'gather_rows', 'scatter_rows', 'bias_relu_', 'relu_bwd_', 'relu_bwd_out', 'halo_plan', 'powerlaw_edges', 'stream_read',
-       'set_spmm_grid_cap', 'noalloc_init', 'version']
+       'set_spmm_grid_cap', 'noalloc_init', 'exchange_new_id', 'exchange_create', 'exchange_begin', 'exchange_end',
+       'exchange_all_gather', 'exchange_destroy', 'version']
 
 
 def _guarded(op):
@@ -143,6 +158,8 @@ EXPORTS = [
     'mh_cheb_terms', 'mh_clenshaw',
     'mh_halo_plan_workspace_bytes', 'mh_halo_plan_count', 'mh_halo_plan_fill',
     'mh_pack', 'mh_unpack', 'mh_gather_rows', 'mh_scatter_rows', 'mh_bias_relu', 'mh_relu_bwd', 'mh_relu_bwd_to',
+    'mh_exchange_id_bytes', 'mh_exchange_new_id', 'mh_exchange_create', 'mh_exchange_begin', 'mh_exchange_end',
+    'mh_exchange_all_gather', 'mh_exchange_destroy',
     'mh_powerlaw_edges', 'mh_stream_read',
 ]
 

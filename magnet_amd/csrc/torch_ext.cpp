@@ -11,6 +11,7 @@
 // `torch.ops.magnet.*` are the calls that replace them.
 #include <cstdint>
 #include <tuple>
+#include <vector>
 
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
@@ -384,6 +385,65 @@ void noalloc_init(int64_t device_index) {
     check_rc(mh_cspmm_noalloc_init(), "cspmm_noalloc_init");
 }
 
+// ---- halo exchange posted from the library (mh_exchange_*) ------------------------------------------
+// The handle travels through Python as an integer; the plan's row lists are kept alive by the caller.
+Tensor exchange_new_id() {
+    Tensor id = at::empty({mh_exchange_id_bytes()}, at::TensorOptions().dtype(at::kByte));
+    check_rc(mh_exchange_new_id(id.data_ptr(), size_t(id.numel())), "exchange_new_id");
+    return id;
+}
+
+int64_t exchange_create(const Tensor& id, int64_t rank, int64_t world, at::TensorList give_rows, at::IntArrayRef recv_ptr,
+                        int64_t n_local, int64_t device_index) {
+    TORCH_CHECK(!id.is_cuda() && id.scalar_type() == at::kByte && id.is_contiguous(), "id must be a contiguous uint8 host tensor");
+    TORCH_CHECK(world >= 1 && int64_t(give_rows.size()) == world && int64_t(recv_ptr.size()) == world + 1,
+                "give_rows needs `world` entries and recv_ptr `world + 1`");
+    const c10::DeviceGuard guard(c10::Device(c10::DeviceType::CUDA, c10::DeviceIndex(device_index)));
+    std::vector<const int32_t*> rows(world, nullptr);
+    std::vector<int64_t> count(world, 0), ptrs(recv_ptr.begin(), recv_ptr.end());
+    for (int64_t p = 0; p < world; ++p) {
+        const Tensor& g = give_rows[p];
+        count[p] = g.numel();
+        if (count[p] > 0) {
+            TORCH_CHECK(g.is_cuda() && g.device().index() == device_index, "give_rows[", p, "] must live on cuda:", device_index);
+            rows[p] = i32(g, "give_rows");
+        }
+    }
+    mh_exchange* x = nullptr;
+    check_rc(mh_exchange_create(id.data_ptr(), size_t(id.numel()), int32_t(rank), int32_t(world), rows.data(), count.data(),
+                                ptrs.data(), n_local, &x), "exchange_create");
+    return reinterpret_cast<int64_t>(x);
+}
+
+void exchange_begin(int64_t handle, const Tensor& own, Tensor& halo) {
+    const c10::DeviceGuard guard(own.device());
+    Planar a = planar(own, "own");
+    need_cuda(halo, "halo");
+    TORCH_CHECK(halo.scalar_type() == at::kFloat && halo.is_contiguous() && (halo.numel() == 0 || (halo.dim() == 3 && halo.size(1) == 2
+                && halo.size(2) == a.f)), "halo must be contiguous float32 [n_halo, 2, F]");
+    check_rc(mh_exchange_begin(reinterpret_cast<mh_exchange*>(handle), a.p, a.ld, a.im, halo.data_ptr<float>(), int32_t(a.f),
+                               stream_of(own)), "exchange_begin");
+}
+
+void exchange_end(int64_t handle, const Tensor& on_device_of) {
+    need_cuda(on_device_of, "on_device_of");
+    const c10::DeviceGuard guard(on_device_of.device());
+    check_rc(mh_exchange_end(reinterpret_cast<mh_exchange*>(handle), stream_of(on_device_of)), "exchange_end");
+}
+
+void exchange_all_gather(int64_t handle, const Tensor& mine, Tensor& all, int64_t world) {
+    need_cuda(mine, "mine"); need_cuda(all, "all");
+    const c10::DeviceGuard guard(mine.device());
+    TORCH_CHECK(mine.scalar_type() == at::kFloat && all.scalar_type() == at::kFloat && mine.is_contiguous() && all.is_contiguous()
+                && all.numel() == world * mine.numel(), "all must be contiguous float32 of world * mine.numel() elements");
+    check_rc(mh_exchange_all_gather(reinterpret_cast<mh_exchange*>(handle), mine.data_ptr<float>(), all.data_ptr<float>(),
+                                    mine.numel(), stream_of(mine)), "exchange_all_gather");
+}
+
+void exchange_destroy(int64_t handle) {
+    check_rc(mh_exchange_destroy(reinterpret_cast<mh_exchange*>(handle)), "exchange_destroy");
+}
+
 // ---- halo plan of a row block ------------------------------------------------------------------
 // (halo_ids [n_halo] ascending global column ids outside [c0, c1) that the block references,
 //  peer_ptr [world + 1]: halo_ids[peer_ptr[p] : peer_ptr[p+1]] lie in rows bounds[p] .. bounds[p+1] of peer p,
@@ -462,6 +522,13 @@ TORCH_LIBRARY(magnet, m) {
     m.def("halo_plan(Tensor col_idx, int n_cols, int c0, int c1, Tensor bounds) -> (Tensor, Tensor, Tensor)");
     m.def("powerlaw_edges(int n_nodes, int seed, int first_edge, Tensor(a!) src, Tensor(b!) dst) -> ()");
     m.def("stream_read(Tensor buf, Tensor(a!) sink) -> ()");
+    m.def("exchange_new_id() -> Tensor", &exchange_new_id);
+    m.def("exchange_create(Tensor id, int rank, int world, Tensor[] give_rows, int[] recv_ptr, int n_local, int device_index) -> int",
+          &exchange_create);
+    m.def("exchange_begin(int handle, Tensor own, Tensor(a!) halo) -> ()", &exchange_begin);
+    m.def("exchange_end(int handle, Tensor on_device_of) -> ()", &exchange_end);
+    m.def("exchange_all_gather(int handle, Tensor mine, Tensor(a!) all, int world) -> ()", &exchange_all_gather);
+    m.def("exchange_destroy(int handle) -> ()", &exchange_destroy);
     m.def("version() -> int", &version);
 }
 

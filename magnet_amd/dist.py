@@ -154,6 +154,17 @@ def start_transfers(ops, group=None):
     return works
 
 
+class _NativeWait:
+    """Handle of an exchange posted by the library (mh_exchange_begin): wait() queues the compute stream's wait."""
+
+    def __init__(self, exchange, on_device_of):
+        self.exchange, self.on_device_of = exchange, on_device_of
+
+    def wait(self):
+        from ._lib import ops
+        ops.exchange_end(self.exchange, self.on_device_of)
+
+
 class TorchRowMover:
     """Index-based stand-in for the halo staging kernels (CPU rehearsal over gloo)."""
 
@@ -305,8 +316,10 @@ class RowPartition:
         self.issue_seconds = None         # a list: host time spent issuing each exchange (packing launches + posting)
         self._gathered = {}               # all_gather mode: feature width -> (staging block, gathered buffer)
         self.L_ext_gathered = None
+        self._exchange = None             # extension mode: handle of the library's exchange object (mh_exchange_*)
 
     MODES = ('overlap', 'overlap_capped', 'sequential', 'all_gather')
+    NATIVE_MODE = 'extension'             # not in MODES: needs RCCL, i.e. one process per GPU
 
     def set_mode(self, mode, int_grid_cap=None):
         """How an order's halo exchange and its two products are arranged:
@@ -317,9 +330,17 @@ class RowPartition:
           'all_gather'      the exchange is ONE all-gather of the ranks' own blocks (padded to the largest block) into a
                             buffer of all rows, which the halo-column product reads through columns renumbered to that
                             buffer; every row travels whether a peer references it or not, so it suits graphs without
-                            locality, where the halo is nearly everything anyway; overlapped like 'overlap'."""
-        if mode not in self.MODES:
-            raise ValueError('mode must be one of %s' % (self.MODES,))
+                            locality, where the halo is nearly everything anyway; overlapped like 'overlap'
+          'extension'       arranged like 'overlap', but an order's packing launches and its grouped RCCL send/receive
+                            are posted by ONE call into the library (mh_exchange_begin, on a communicator and a stream
+                            the library owns) and the wait by another (mh_exchange_end): no torch.distributed objects
+                            and no interpreter time between the kernels and the communication library.  GPU tensors
+                            and one process per GPU only (RCCL refuses two ranks on one device); the first use is a
+                            collective (the communicator is created then)."""
+        if mode not in self.MODES and mode != self.NATIVE_MODE:
+            raise ValueError('mode must be one of %s' % (self.MODES + (self.NATIVE_MODE,),))
+        if mode == self.NATIVE_MODE and self.world > 1 and self._exchange is None:
+            self._exchange = self._create_native_exchange()
         self.mode = mode
         if int_grid_cap is not None:
             self.int_grid_cap = int(int_grid_cap)
@@ -334,6 +355,27 @@ class RowPartition:
             self.L_ext_gathered = self._make_operator(rpe, slot_to_gathered[(cie - self.n_local).long()], ve,
                                                       self.world * self.max_rows)
         return self
+
+    def _create_native_exchange(self):
+        from ._lib import ops
+        dev = self.halo_ids.device
+        if dev.type != 'cuda':
+            raise ValueError("mode 'extension' posts RCCL transfers of GPU tensors; this partition lives on %s" % dev)
+        # the communicator's id is made on rank 0 and carried to the others over the group the partition already has
+        id_ = ops.exchange_new_id().to(torch.int32) if self.rank == 0 else torch.zeros(128, dtype=torch.int32)
+        id_ = all_reduce(id_.to(dev), group=self.group).to('cpu', torch.uint8)
+        empty = torch.empty(0, dtype=torch.int32, device=dev)
+        self._give_rows = [empty if (p == self.rank or g is None) else g.contiguous() for p, g in enumerate(self.give)]
+        return ops.exchange_create(id_, self.rank, self.world, self._give_rows, self.peer_ptr, self.n_local, dev.index)
+
+    def close(self):
+        """Destroys the library's exchange object, if one was made (communicator, stream, staging memory)."""
+        if self._exchange is not None:
+            from ._lib import ops
+            handle, self._exchange = self._exchange, None
+            if self.mode == self.NATIVE_MODE:
+                self.mode = 'overlap'
+            ops.exchange_destroy(handle)
 
     def _gather_buffers(self, f, device, dtype):
         bufs = self._gathered.get(f)
@@ -385,6 +427,10 @@ class RowPartition:
             stage, gathered = self._gather_buffers(own.size(2), own.device, own.dtype)
             stage[:self.n_local].copy_(own)
             return ([start_all_gather(gathered, stage, self.group)], [stage])
+        if self.mode == self.NATIVE_MODE:
+            from ._lib import ops as native
+            native.exchange_begin(self._exchange, own, halo)
+            return ([_NativeWait(self._exchange, own)], [own, halo])
         ops, staged = [], []
         nl, pp = self.n_local, self.peer_ptr
         for step in range(1, self.world):

@@ -105,6 +105,122 @@ def test_ranks_sharing_one_gpu_match_the_single_gpu_result(world, weighted, tmp_
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+MOCK_RCCL = os.path.join(ROOT, 'tests', 'abi', 'libmock_rccl.so')
+
+
+def _worker_native(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['MAGNET_RCCL_LIBRARY'] = MOCK_RCCL            # RCCL refuses ranks that share a device; see tests/abi/mock_rccl.cpp
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from magnet_amd import dist as D
+        from magnet_amd.laplacian import MagneticLaplacian, build_magnetic_laplacian, powerlaw_edges
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        make = lambda rp, ci, v, nc: MagneticLaplacian(rp, ci, v, nc)
+        report = {}
+        for name in ('sparse', 'dense'):
+            if name == 'sparse':        # peers take subsets of the block: packed sends
+                n = N
+                blk, bounds = D.build_row_block(_chunks(dev, False), n, rank, world, q=0.2)
+                part = D.RowPartition(blk.row_ptr, blk.col_idx, blk.val, n, bounds, rank, world, make)
+            else:                       # every rank references every remote row: the block itself is sent, in place
+                n = 96
+                src, dst = powerlaw_edges(n, 6000, 4, device=dev)
+                src = (src + dst * 7) % n
+                L = build_magnetic_laplacian(src, dst, n, q=0.2)
+                part = D.RowPartition.from_global(L.row_ptr, L.col_idx, L.val, n, rank, world, make,
+                                                  bounds=[n * r // world for r in range(world + 1)])
+            x = torch.randn(n, 2, F, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+            def run():
+                xb = part.new_buffer(F, dev); xb.fill_(float('nan'))
+                part.block(xb).copy_(x[part.r0:part.r1])
+                zs = [part.block(z).clone() for z in part.cheb_terms(xb, TERMS)]          # contiguous operands
+                block = torch.full((part.n_local, 2, TERMS, F), float('nan'), device=dev)
+                block[:, :, 0] = x[part.r0:part.r1]
+                part.cheb_block(block)                                                     # strided operands: one order of a block
+                back = part.clenshaw([block[:, :, k] for k in range(TERMS)])
+                torch.cuda.synchronize()
+                return zs, block.clone(), back.clone()
+
+            part.set_mode('overlap')
+            want = run()
+            part.set_mode('extension')
+            got = run()
+            got2 = run()                                                                   # the object is reused call after call
+            same = all(torch.equal(a, b) for a, b in zip(want[0], got[0])) and torch.equal(want[1], got[1]) \
+                and torch.equal(want[2], got[2]) and torch.equal(want[1], got2[1]) and torch.equal(want[2], got2[2])
+            in_place = sum(int(g.numel() == part.n_local) for p, g in enumerate(part.give) if p != rank and g is not None)
+            report[name] = {'same': bool(same), 'finite': bool(torch.isfinite(got[1]).all()), 'in_place_peers': in_place,
+                            'n_halo': part.n_halo}
+            part.close()
+            assert part.mode == 'overlap' and part._exchange is None
+        torch.save(report, os.path.join(out_dir, 'n%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_exchange_posted_by_the_library_between_ranks_sharing_one_gpu(world, tmp_path):
+    """mh_exchange_* (packing + grouped send/receive posted from native code, on the library's own stream) with 2 and 3
+    real processes: forward recursion on contiguous and on strided operands and the Clenshaw backward give bit for bit
+    what the torch.distributed path gives.  The transport under the library is the shared-memory stand-in for RCCL
+    (one GPU here); the real RCCL is exercised by the single-rank test below."""
+    assert os.path.exists(MOCK_RCCL), 'tests/abi/libmock_rccl.so is not built (make -C magnet_amd/csrc)'
+    mp.spawn(_worker_native, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        rep = torch.load(os.path.join(str(tmp_path), 'n%d.pt' % r))
+        assert rep['sparse']['same'] and rep['sparse']['finite'] and rep['sparse']['n_halo'] > 0, rep
+        assert rep['dense']['same'] and rep['dense']['finite'] and rep['dense']['in_place_peers'] == world - 1, rep
+
+
+def test_exchange_posted_by_the_library_over_the_real_rccl_single_rank():
+    """The same entry points over the real RCCL with a communicator of one rank that serves itself: rows gathered from
+    a strided block land in the halo buffer, a whole contiguous block is sent in place, an all-gather of one rank copies
+    — the loading of the library, the communicator, the grouped calls and the stream ordering are the production ones."""
+    script = r"""
+import torch
+from magnet_amd._lib import ops
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+g = torch.Generator(device=dev).manual_seed(1)
+n, f, terms = 5000, 48, 3
+block = torch.randn(n, 2, terms, f, device=dev, generator=g)
+rows = torch.randperm(n, device=dev, generator=g)[:1234].sort().values.to(torch.int32)
+ident = ops.exchange_new_id()
+h = ops.exchange_create(ident, 0, 1, [rows], [0, rows.numel()], n, 0)
+halo = torch.full((rows.numel(), 2, f), float('nan'), device=dev)
+for k in (1, 2, 1):
+    own = block[:, :, k]
+    ops.exchange_begin(h, own, halo)
+    busy = torch.mm(torch.randn(512, 512, device=dev), torch.randn(512, 512, device=dev))     # overlaps the transfer
+    ops.exchange_end(h, halo)
+    assert torch.equal(halo, own[rows.long()]), 'packed rows, order %d' % k
+ops.exchange_destroy(h)
+everything = torch.arange(n, device=dev, dtype=torch.int32)
+h = ops.exchange_create(ops.exchange_new_id(), 0, 1, [everything], [0, n], n, 0)
+own = torch.randn(n, 2, f, device=dev, generator=g)
+halo = torch.empty(n, 2, f, device=dev)
+ops.exchange_begin(h, own, halo)
+ops.exchange_end(h, halo)
+assert torch.equal(halo, own), 'block sent in place'
+out = torch.empty(n * 2 * f, device=dev)
+ops.exchange_all_gather(h, own.view(-1), out, 1)
+ops.exchange_end(h, out)
+assert torch.equal(out, own.view(-1)), 'all-gather of one rank'
+ops.exchange_destroy(h)
+torch.cuda.synchronize()
+print('native exchange ok')
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('MAGNET_RCCL_LIBRARY', None)
+    res = subprocess.run([sys.executable, '-c', script], cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 0 and 'native exchange ok' in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+
+
 def _train_setup(dev):
     g = torch.Generator().manual_seed(8)
     cin, ncls = 6, 4
@@ -181,7 +297,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     ranks on this GPU over gloo: the whole multi-rank control flow (per-rank build, strategy record, timed steps,
     compute-only steps, the row-partition variants, the epoch in both layouts, the CPU baseline on rank 0) ends with
     one JSON line on rank 0 that carries every field the first run on several GPUs is meant to decide from."""
-    env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # the leg whose exchanges the library posts itself runs over the shared-memory stand-in for RCCL (one GPU here)
+    env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MAGNET_RCCL_LIBRARY=MOCK_RCCL,
+               MOCK_RCCL_SLOT_BYTES=str(128 << 20))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--nodes', '200000',
            '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy,
@@ -211,6 +329,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     assert v['overlap_capped']['own_column_product_workgroups'] > 0 and v['compute_only_ms_per_step'] > 0
     assert v['all_gather']['rows_received_per_rank_per_order'] >= rl['largest_halo_rows']
     assert d['row_partition']['ms_per_step'] == v['overlap']['ms_per_step']
+    x = v['extension']
+    assert x['ms_per_step'] > 0 and x['max_abs_difference_from_overlap'] == 0.0 and len(x['exposed_wait_ms_per_order']) == 3, x
     # the epoch in both layouts, the row one over blocks the ranks built for themselves
     ep = d['epoch']
     assert ep['ms'] > 0 and ep['n_gpus'] == 2 and set(ep['layouts']) == {'rows', 'cols'}
