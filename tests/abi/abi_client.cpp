@@ -3,12 +3,17 @@
 // deterministic digraph, applies one propagation order through the plain and the no-allocation entry points, and
 // prints the CSR and the result as text; tests/test_gpu_parity.py compares that text with the CPU oracle.
 //
-//   abi_client <n_nodes> <n_edges> <F> <q>
+//   abi_client <n_nodes> <n_edges> <F> <q> [exchange]
+//
+// With `exchange`, the result's rows 0, 3, 6, ... are then served to this same process through mh_exchange_* — a
+// one-rank RCCL communicator that sends to itself: the library finds and loads RCCL on its own (no torch in the
+// process), posts the packed rows on its stream, and the halo buffer must hold exactly those rows ("exchange ok").
 //
 // edges: e -> (src, dst) = ((7 e + 3) mod n, (e * e + 5 e + 1) mod n); features X[i][part][c] = sin(0.37 i + 1.1 c + 0.5 part)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -64,5 +69,35 @@ int main(int argc, char** argv) {
     printf("col"); for (int64_t i = 0; i < nnz; ++i) printf(" %d", col[i]); printf("\n");
     printf("val"); for (int64_t i = 0; i < 2 * nnz; ++i) printf(" %.9g", val[i]); printf("\n");
     printf("y"); for (size_t i = 0; i < y.size(); ++i) printf(" %.9g", y[i]); printf("\n");
+    if (argc >= 6 && std::string(argv[5]) == "exchange") {
+        std::vector<int32_t> rows;
+        for (int i = 0; i < n; i += 3) rows.push_back(i);
+        int32_t* d_rows; float* d_halo;
+        HIP_OK(hipMalloc(&d_rows, rows.size() * 4));
+        HIP_OK(hipMemcpy(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&d_halo, rows.size() * 2 * F * 4));
+        HIP_OK(hipMemset(d_halo, 0xff, rows.size() * 2 * F * 4));
+        std::vector<unsigned char> id(mh_exchange_id_bytes());
+        MH_CALL(mh_exchange_new_id(id.data(), id.size()));
+        const int32_t* give_rows[1] = {d_rows};
+        const int64_t give_count[1] = {int64_t(rows.size())};
+        const int64_t recv_ptr[2] = {0, int64_t(rows.size())};
+        mh_exchange* ex = nullptr;
+        MH_CALL(mh_exchange_create(id.data(), id.size(), 0, 1, give_rows, give_count, recv_ptr, n, &ex));
+        hipStream_t compute;
+        HIP_OK(hipStreamCreate(&compute));
+        for (int rep = 0; rep < 2; ++rep) {
+            MH_CALL(mh_exchange_begin(ex, d_y, 2 * F, F, d_halo, F, compute));
+            MH_CALL(mh_exchange_end(ex, compute));
+        }
+        HIP_OK(hipStreamSynchronize(compute));
+        std::vector<float> halo(rows.size() * 2 * F);
+        HIP_OK(hipMemcpy(halo.data(), d_halo, halo.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < rows.size(); ++r)
+            for (int j = 0; j < 2 * F; ++j)
+                if (halo[r * 2 * F + j] != y[size_t(rows[r]) * 2 * F + j]) { fprintf(stderr, "halo row %zu differs\n", r); return 5; }
+        MH_CALL(mh_exchange_destroy(ex));
+        printf("exchange ok\n");
+    }
     return 0;
 }

@@ -596,6 +596,18 @@ def test_c_abi_from_a_plain_cpp_caller():
     assert_close(y[:, 0], want.real); assert_close(y[:, 1], want.imag)
 
 
+def test_c_abi_exchange_from_a_plain_cpp_caller():
+    """The same program with `exchange`: mh_exchange_* from a process without torch — the library loads RCCL by itself,
+    creates a one-rank communicator that serves itself, and the halo buffer receives exactly the packed rows."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, 'tests', 'abi', 'abi_client')
+    assert os.path.isfile(exe), 'tests/abi/abi_client is not built (make -C magnet_amd/csrc)'
+    env = {k: v for k, v in os.environ.items() if k != 'MAGNET_RCCL_LIBRARY'}
+    res = subprocess.run([exe, '300', '5000', '8', '0.25', 'exchange'], capture_output=True, text=True, timeout=150, env=env)
+    assert res.returncode == 0 and res.stdout.strip().endswith('exchange ok'), (res.stdout[-200:], res.stderr[-1000:])
+
+
 def test_magnetconv_edge_index_signature():
     _, lap, H, M, O = _mods()
     row, col, n, _ = _telegram(0.25, False)
