@@ -141,17 +141,43 @@ __device__ inline float inv_sqrt_degree(double sum) {
     return float(1.0 / sqrt(double(d)));           // d^-1/2 rounded once (hermitian.py:152)
 }
 
+// Weighted degrees: the row's weights summed in double precision.  A wavefront takes four rows, 16 lanes each (the
+// average row has a few dozen records); a row of more than kShortRow records is left to the whole wavefront afterwards,
+// with four independent partial sums per lane so that its loads are in flight together (one hub row would otherwise
+// set the kernel's duration: a single chain of dependent iterations).  The summation order is fixed, so a row's
+// value is the same in a whole-graph build and in a row-block build.
+constexpr int kShortRow = 512;
+
 __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_weighted(const int32_t* __restrict__ rec_ptr,
                                                                    const float* __restrict__ w_sorted,
                                                                    int32_t n_nodes, float* __restrict__ dinv) {
-    const int lane = threadIdx.x & 63;
-    int64_t r = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-    if (r >= n_nodes) return;
-    int32_t a = rec_ptr[r], b = rec_ptr[r + 1];
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+    const int64_t r = wave * 4 + sub;
+    int32_t a = 0, b = 0;
+    if (r < n_nodes) { a = rec_ptr[r]; b = rec_ptr[r + 1]; }
+    const bool is_long = b - a > kShortRow;
     double part = 0.0;
-    for (int32_t p = a + lane; p < b; p += 64) part += double(w_sorted[p]);
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) dinv[r] = inv_sqrt_degree(part);
+    if (!is_long)
+        for (int32_t p = a + sl; p < b; p += 16) part += double(w_sorted[p]);
+    for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);      // stays inside the 16 lanes
+    if (r < n_nodes && !is_long && sl == 0) dinv[r] = inv_sqrt_degree(part);
+    uint64_t todo = __ballot(is_long && sl == 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int32_t la = __shfl(a, src, 64), lb = __shfl(b, src, 64);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int32_t p = la + lane;
+        for (; p + 192 < lb; p += 256) {
+            s0 += double(w_sorted[p]); s1 += double(w_sorted[p + 64]);
+            s2 += double(w_sorted[p + 128]); s3 += double(w_sorted[p + 192]);
+        }
+        for (; p < lb; p += 64) s0 += double(w_sorted[p]);
+        double s = (s0 + s1) + (s2 + s3);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) dinv[wave * 4 + (src >> 4)] = inv_sqrt_degree(s);
+    }
 }
 
 // d^-1/2 for every record count a tagged key can carry (the emission looks a column's value up here instead of
@@ -589,7 +615,7 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int
     }
     if (n_nodes > 0) {
         if (weighted)
-            degree_inv_sqrt_weighted<<<grid_for(int64_t(n_nodes) * 64), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
+            degree_inv_sqrt_weighted<<<grid_for((int64_t(n_nodes) + 3) / 4 * 64), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
         else
             degree_inv_sqrt_counts<<<grid_for(n_nodes), kBlock, 0, stream>>>(W.rec_ptr, n_nodes, W.dinv);
         MH_LAUNCH_CHECK("degree_inv_sqrt");

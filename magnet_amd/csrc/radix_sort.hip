@@ -92,11 +92,18 @@ __global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist,
     __shared__ uint32_t wave_total[kBins / 64];
     const int d = threadIdx.x, lane = d & 63, w = d >> 6;
     uint32_t before = 0, total = 0;
-#pragma unroll 8
-    for (int64_t c = 0; c < n_chunks; ++c) {            // independent loads: issued in batches
-        const uint32_t v = chunk_sum[c * kBins + d];
-        before += c < int64_t(blockIdx.x) ? v : 0u;
-        total += v;
+    // every load below is independent of the one before it; they are issued kBatch at a time, so the kernel spends
+    // (chunks + tiles per chunk) / kBatch memory latencies instead of one per load
+    constexpr int kBatch = 32;
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) v[j] = c0 + j < n_chunks ? chunk_sum[(c0 + j) * kBins + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            before += c0 + j < int64_t(blockIdx.x) ? v[j] : 0u;
+            total += v[j];
+        }
     }
     uint32_t inc = total;                               // exclusive scan of the digit totals
 #pragma unroll
@@ -111,10 +118,15 @@ __global__ void __launch_bounds__(kBins) scan_apply(uint32_t* __restrict__ hist,
     const int64_t t0 = int64_t(blockIdx.x) * kChunk;
     const int64_t t1 = t0 + kChunk < n_tiles ? t0 + kChunk : n_tiles;
     uint32_t run = digit_base + before;
-    for (int64_t t = t0; t < t1; ++t) {
-        uint32_t v = hist[t * kBins + d];
-        hist[t * kBins + d] = run;
-        run += v;
+    for (int64_t t = t0; t < t1; t += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) v[j] = t + j < t1 ? hist[(t + j) * kBins + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (t + j < t1) hist[(t + j) * kBins + d] = run;
+            run += v[j];
+        }
     }
 }
 
