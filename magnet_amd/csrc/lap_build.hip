@@ -143,25 +143,37 @@ __device__ inline float inv_sqrt_degree(double sum) {
 
 // Weighted degrees: the row's weights summed in double precision.  A wavefront takes four rows, 16 lanes each (the
 // average row has a few dozen records); a row of more than kShortRow records is left to the whole wavefront afterwards,
-// with four independent partial sums per lane so that its loads are in flight together (one hub row would otherwise
-// set the kernel's duration: a single chain of dependent iterations).  The summation order is fixed, so a row's
-// value is the same in a whole-graph build and in a row-block build.
+// and one of more than kWaveRow to the whole workgroup, with four independent partial sums per lane so that the loads
+// are in flight together (a hub row walked by 16 or 64 lanes would set the kernel's duration: one chain of dependent
+// iterations).  The summation order is a fixed function of the row's length, so a row's value is the same in a
+// whole-graph build and in a row-block build.
 constexpr int kShortRow = 512;
+constexpr int kWaveRow = 8192;
 
 __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_weighted(const int32_t* __restrict__ rec_ptr,
                                                                    const float* __restrict__ w_sorted,
                                                                    int32_t n_nodes, float* __restrict__ dinv) {
-    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
-    const int64_t wave = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 6;
-    const int64_t r = wave * 4 + sub;
+    constexpr int kRowsPerBlock = kBlock / 16;
+    __shared__ int32_t hub_a[kRowsPerBlock], hub_b[kRowsPerBlock], hub_r[kRowsPerBlock];
+    __shared__ int hub_n;
+    __shared__ double wave_sum[kBlock / 64];
+    if (threadIdx.x == 0) hub_n = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sl = lane & 15;
+    const int64_t r = int64_t(blockIdx.x) * kRowsPerBlock + (threadIdx.x >> 4);
     int32_t a = 0, b = 0;
     if (r < n_nodes) { a = rec_ptr[r]; b = rec_ptr[r + 1]; }
-    const bool is_long = b - a > kShortRow;
+    const bool is_hub = b - a > kWaveRow;
+    const bool is_long = b - a > kShortRow && !is_hub;
+    if (is_hub && sl == 0) {
+        const int i = atomicAdd(&hub_n, 1);
+        hub_a[i] = a; hub_b[i] = b; hub_r[i] = int32_t(r);
+    }
     double part = 0.0;
-    if (!is_long)
+    if (b - a <= kShortRow)
         for (int32_t p = a + sl; p < b; p += 16) part += double(w_sorted[p]);
     for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);      // stays inside the 16 lanes
-    if (r < n_nodes && !is_long && sl == 0) dinv[r] = inv_sqrt_degree(part);
+    if (r < n_nodes && b - a <= kShortRow && sl == 0) dinv[r] = inv_sqrt_degree(part);
     uint64_t todo = __ballot(is_long && sl == 0);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
@@ -176,7 +188,30 @@ __global__ void __launch_bounds__(kBlock) degree_inv_sqrt_weighted(const int32_t
         for (; p < lb; p += 64) s0 += double(w_sorted[p]);
         double s = (s0 + s1) + (s2 + s3);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) dinv[wave * 4 + (src >> 4)] = inv_sqrt_degree(s);
+        const int64_t lr = __shfl(r, src, 64);
+        if (lane == 0) dinv[lr] = inv_sqrt_degree(s);
+    }
+    __syncthreads();
+    const int hubs = hub_n;
+    for (int i = 0; i < hubs; ++i) {
+        const int32_t la = hub_a[i], lb = hub_b[i];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int32_t p = la + int32_t(threadIdx.x);
+        for (; p + 3 * kBlock < lb; p += 4 * kBlock) {
+            s0 += double(w_sorted[p]); s1 += double(w_sorted[p + kBlock]);
+            s2 += double(w_sorted[p + 2 * kBlock]); s3 += double(w_sorted[p + 3 * kBlock]);
+        }
+        for (; p < lb; p += kBlock) s0 += double(w_sorted[p]);
+        double s = (s0 + s1) + (s2 + s3);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) wave_sum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / 64; ++w) t += wave_sum[w];
+            dinv[hub_r[i]] = inv_sqrt_degree(t);
+        }
+        __syncthreads();
     }
 }
 
@@ -615,7 +650,7 @@ int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int
     }
     if (n_nodes > 0) {
         if (weighted)
-            degree_inv_sqrt_weighted<<<grid_for((int64_t(n_nodes) + 3) / 4 * 64), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
+            degree_inv_sqrt_weighted<<<grid_for(int64_t(n_nodes) * 16), kBlock, 0, stream>>>(W.rec_ptr, W.w1, n_nodes, W.dinv);
         else
             degree_inv_sqrt_counts<<<grid_for(n_nodes), kBlock, 0, stream>>>(W.rec_ptr, n_nodes, W.dinv);
         MH_LAUNCH_CHECK("degree_inv_sqrt");

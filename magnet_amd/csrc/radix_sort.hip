@@ -70,10 +70,24 @@ __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __res
     if (threadIdx.x < kBins) bins[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = int64_t(blockIdx.x) * kTile;
+    if (GEN == 0 && base + kTile <= n) {
+        // a full tile of keys in memory: 16 bytes per lane and load, all loads issued before the first count
+        // (a histogram does not care which lane sees which key)
+        const ulonglong2* __restrict__ pairs = reinterpret_cast<const ulonglong2*>(keys + base);
+        ulonglong2 k[kItems / 2];
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        int64_t idx = base + i * kThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
+        for (int i = 0; i < kItems / 2; ++i) k[i] = pairs[i * kThreads + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < kItems / 2; ++i) {
+            atomicAdd(&bins[digit_of(k[i].x, shift, mask)], 1u);
+            atomicAdd(&bins[digit_of(k[i].y, shift, mask)], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            int64_t idx = base + i * kThreads + threadIdx.x;
+            if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < kBins) {
