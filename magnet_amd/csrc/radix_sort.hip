@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __res
     if (threadIdx.x < kBins) bins[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = int64_t(blockIdx.x) * kTile;
-    if (GEN == 0 && base + kTile <= n) {
+    if (GEN == 0 && base + kTile <= n && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0) {
         // a full tile of keys in memory: 16 bytes per lane and load, all loads issued before the first count
         // (a histogram does not care which lane sees which key)
         const ulonglong2* __restrict__ pairs = reinterpret_cast<const ulonglong2*>(keys + base);
