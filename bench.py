@@ -642,9 +642,15 @@ def main():
     def give_up():
         if stage[0] == 'extension':
             if out is not None and isinstance(dist_info.get('row_variants'), dict):
-                dist_info['row_variants']['extension'] = {'error': 'did not finish within 150 s'}
-            sys.stderr.write('bench.py: the library-posted exchange did not finish within 150 s; line printed without it\n')
+                dist_info['row_variants']['extension'] = {'error': 'did not finish within its time limit'}
+            sys.stderr.write('bench.py: the library-posted exchange did not finish within its time limit; line printed without it\n')
             sys.stderr.flush()
+            if rank == 0 and not args.no_cpu_baseline:      # the rest of the line is owed regardless (this thread is free:
+                args.full_nnz = nnz_total                   # a stuck GPU call holds no interpreter lock)
+                try:
+                    out['cpu_baseline'] = cpu_baseline(args)
+                except Exception as ex:
+                    out['cpu_baseline'] = {'error': repr(ex)[:300]}
             emit()
             os._exit(0)
         if out is not None:
@@ -712,7 +718,7 @@ def main():
     watchdog.cancel()
     if multi and rconv is not None and (backend == 'nccl' or os.environ.get('MAGNET_RCCL_LIBRARY')):
         stage[0] = 'extension'
-        watchdog = threading.Timer(150.0, give_up)
+        watchdog = threading.Timer(float(os.environ.get('MH_EXTENSION_LIMIT_S', '150')), give_up)
         watchdog.daemon = True
         watchdog.start()
         note(rank, 'row partition with the exchange posted by the library')

@@ -104,6 +104,9 @@ ncclResult_t run(ncclComm* c, const Pending& p) {
 }
 
 ncclResult_t flush() {
+    // MOCK_RCCL_STALL: never complete (a test of the caller's own time limit)
+    if (const char* e = std::getenv("MOCK_RCCL_STALL"))
+        if (*e) std::this_thread::sleep_for(std::chrono::hours(1));
     std::vector<std::pair<ncclComm*, Pending>> q;
     q.swap(t_queue);
     for (auto& e : q)

@@ -342,3 +342,23 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     assert ep['ms'] == min(ep['layouts'][l]['ms'] for l in ep['layouts'])
     # the CPU baseline is reported at every N
     assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['kind'] == 'port'
+
+
+def test_bench_line_survives_a_stuck_library_exchange():
+    """The leg whose exchanges the library posts runs last and under its own time limit: with a communication library
+    that never completes (the stand-in, told to stall) rank 0 still prints the whole line — every other field, the CPU
+    baseline included — records the leg as unfinished, and the run ends with status 0."""
+    env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MAGNET_RCCL_LIBRARY=MOCK_RCCL,
+               MOCK_RCCL_STALL='1', MH_EXTENSION_LIMIT_S='8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--nodes', '100000',
+           '--edges', '2000000', '--features', '32', '--K', '2', '--strategy', 'rows',
+           '--cpu-sample-nodes', '20000', '--cpu-sample-edges', '200000', '--epoch-nodes', '30000', '--epoch-edges', '600000']
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-500:]
+    d = json.loads(lines[0])
+    v = d['multi_gpu']['row_variants']
+    assert 'error' in v['extension'] and v['overlap']['ms_per_step'] > 0
+    assert d['epoch']['ms'] > 0 and d['cpu_baseline']['value'] > 0 and d['value'] > 0
