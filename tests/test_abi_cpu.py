@@ -87,3 +87,46 @@ def test_int32_range_is_checked_before_any_memory_is_touched():
     rc = lib.mh_cspmm_planned(fake, fake, fake, 10, fake, 8, 4, C.c_void_p(8192), 8, 4, 1.0, None, 0, 0, 0.0, None, 0, 0, 0.0,
                               None, 0, None, 4, fake, 3, 2, 512, fake, 1 << 20, None)
     assert rc == -1 and b'plan' in lib.mh_last_error()
+
+
+def test_header_is_plain_c():
+    """include/magnet_hip.h is what a C caller binds: it must compile as C99 on its own."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'use.c')
+        open(src, 'w').write('#include "magnet_hip.h"\nint main(void) { return mh_version() > 0 ? 0 : 1; }\n')
+        res = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only',
+                              '-I', os.path.join(ROOT, 'include'), src], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
+def test_exchange_entry_points_check_their_arguments_and_report_a_missing_rccl():
+    """mh_exchange_*: bad plans are refused before anything is loaded; a communication library that cannot be loaded is
+    an error code with a message (MH_ERR_COMM), not a crash, and leaves the rest of the library usable."""
+    import subprocess
+    import sys
+    from magnet_amd import _lib
+    lib = _lib.lib
+    assert lib.mh_exchange_id_bytes() == 128
+    small = (C.c_ubyte * 16)()
+    assert lib.mh_exchange_new_id(small, 16) == -1 and b'128' in lib.mh_last_error()
+    ident = (C.c_ubyte * 128)()
+    out = C.c_void_p()
+    rows = (C.c_void_p * 2)(None, None)
+    count = (C.c_int64 * 2)(0, 0)
+    ptr = (C.c_int64 * 3)(0, 0, 0)
+    assert lib.mh_exchange_create(ident, 128, 2, 2, rows, count, ptr, 10, C.byref(out)) == -1      # rank outside the world
+    count[1] = 11
+    assert lib.mh_exchange_create(ident, 128, 0, 2, rows, count, ptr, 10, C.byref(out)) == -1      # more rows than the block has
+    assert b'give_count' in lib.mh_last_error() and not out.value
+    assert lib.mh_exchange_begin(None, None, 0, 0, None, 4, None) == -1
+    assert lib.mh_exchange_end(None, None) == -1
+    assert lib.mh_exchange_destroy(None) == 0
+    code = ("import ctypes as C\nfrom magnet_amd import _lib\nb = (C.c_ubyte * 128)()\n"
+            "rc = _lib.lib.mh_exchange_new_id(b, 128)\nprint(rc, _lib.lib.mh_last_error().decode())\n"
+            "assert _lib.lib.mh_version() >= 300\n")
+    env = dict(os.environ, MAGNET_RCCL_LIBRARY='/nonexistent/librccl.so')
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-500:]
+    assert res.stdout.startswith('-6 ') and 'could not be loaded' in res.stdout, res.stdout
