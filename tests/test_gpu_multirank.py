@@ -362,3 +362,30 @@ def test_bench_line_survives_a_stuck_library_exchange():
     v = d['multi_gpu']['row_variants']
     assert 'error' in v['extension'] and v['overlap']['ms_per_step'] > 0
     assert d['epoch']['ms'] > 0 and d['cpu_baseline']['value'] > 0 and d['value'] > 0
+
+
+@pytest.mark.parametrize('strategy', ['rows', 'auto'])
+def test_bench_eight_rank_rehearsal_on_one_gpu(strategy):
+    """bench.py --gpus 8 launched as the driver launches it, all eight ranks on this GPU (gloo, host-staged transfers, the
+    library-posted exchange over the shared-memory stand-in): the eight-rank bookkeeping — bounds, column slices of 64 / 8
+    features, seven peers per exchange, both epoch layouts — runs to the end and fills every field."""
+    env = dict(os.environ, MH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MAGNET_RCCL_LIBRARY=MOCK_RCCL,
+               MOCK_RCCL_SLOT_BYTES=str(32 << 20), OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1', '--nodes', '200000',
+           '--edges', '4000000', '--features', '64', '--K', '3', '--strategy', strategy,
+           '--cpu-sample-nodes', '20000', '--cpu-sample-edges', '200000', '--epoch-nodes', '50000', '--epoch-edges', '1000000']
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=250)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-500:]
+    d = json.loads(lines[0])
+    m = d['multi_gpu']
+    assert d['n_gpus'] == 8 and m['ranks_initialised'] == 8 and d['value'] > 0
+    assert d['config']['parallelism'] == ('rows8' if strategy == 'rows' else m['strategy'] + '8')
+    v = m['row_variants']
+    for mode in ('overlap', 'overlap_capped', 'sequential', 'all_gather', 'extension'):
+        assert v[mode]['ms_per_step'] > 0 and len(v[mode]['exposed_wait_ms_per_order']) == 3, (mode, v[mode])
+    assert v['extension']['max_abs_difference_from_overlap'] == 0.0
+    assert set(d['epoch']['layouts']) == {'rows', 'cols'} and all(e['ms'] > 0 for e in d['epoch']['layouts'].values())
+    assert d['cpu_baseline']['value'] > 0
