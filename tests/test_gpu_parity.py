@@ -577,7 +577,7 @@ def test_c_abi_from_a_plain_cpp_caller():
     exe = os.path.join(ROOT, 'tests', 'abi', 'abi_client')
     assert os.path.isfile(exe), 'tests/abi/abi_client is not built (make -C magnet_amd/csrc)'
     n, e, f, q = 300, 5000, 8, 0.25
-    res = subprocess.run([exe, str(n), str(e), str(f), str(q)], capture_output=True, text=True, timeout=100)
+    res = subprocess.run([exe, str(n), str(e), str(f), str(q)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-1000:]
     lines = {l.split(' ', 1)[0]: l.split(' ')[1:] for l in res.stdout.strip().splitlines()}
     i = np.arange(e, dtype=np.int64)
@@ -604,7 +604,7 @@ def test_c_abi_exchange_from_a_plain_cpp_caller():
     exe = os.path.join(ROOT, 'tests', 'abi', 'abi_client')
     assert os.path.isfile(exe), 'tests/abi/abi_client is not built (make -C magnet_amd/csrc)'
     env = {k: v for k, v in os.environ.items() if k != 'MAGNET_RCCL_LIBRARY'}
-    res = subprocess.run([exe, '300', '5000', '8', '0.25', 'exchange'], capture_output=True, text=True, timeout=150, env=env)
+    res = subprocess.run([exe, '300', '5000', '8', '0.25', 'exchange'], capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0 and res.stdout.strip().endswith('exchange ok'), (res.stdout[-200:], res.stderr[-1000:])
 
 
