@@ -90,14 +90,22 @@ def builder_bytes(e, n, nnz, passes):
     a side list (not counted: none on this workload).  d^-1/2 of an entry's column comes from the record count its key
     carries (unweighted whole-graph builds with whole column passes; a random 4-byte read per nonzero otherwise, not
     counted)."""
+    return sum(builder_bytes_split(e, n, nnz, passes))
+
+
+def builder_bytes_split(e, n, nnz, passes):
+    """builder_bytes in two parts: bytes of the kernels that essentially only read (histograms, group starts, segments,
+    flag scan, row_ptr) and bytes of those that read and write in equal measure (the scatters, the emission).  The
+    first kind can approach the device's read-only streaming rate, the second its copy rate."""
     m = 2 * e
-    sort = passes * 24 * m
+    histograms = passes * 8 * m
+    scatters = passes * 16 * m
     starts = 8 * (n + 1)
     segments = 8 * m + m // 8
     flag_scan = 2 * (m // 8) + m // 16
     row_ptr = 20 * (n + 1)
     emission = 8 * m + m // 8 + m // 16 + 12 * nnz
-    return sort + starts + segments + flag_scan + row_ptr + emission
+    return histograms + starts + segments + flag_scan + row_ptr, scatters + emission
 
 
 def file_sha256(path):
@@ -588,6 +596,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         passes = (2 * max(1, (n - 1).bit_length()) + 7) // 8
         b_bytes = builder_bytes(e, n, nnz_total, passes)
+        b_read, b_copy = builder_bytes_split(e, n, nnz_total, passes)
+        b_floor_ms = (b_read / ceiling['read'] + b_copy / ceiling['copy']) / 1e6 if ceiling else None
         out = {
             'metric': 'MagNetConv edges/s', 'value': nnz_total * K / (elapsed / args.steps), 'unit': 'edges/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -620,6 +630,10 @@ def main():
                 'bytes_model': b_bytes, 'sort_passes': passes,
                 'achieved': b_bytes / (build_device_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': b_bytes / (build_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'floor_ms_at_measured_ceilings': b_floor_ms,
+                'frac_of_floor_at_measured_ceilings': None if b_floor_ms is None else b_floor_ms / build_device_ms,
+                'floor_note': 'read-mostly kernels at the read-only streaming rate measured in this run, read+write kernels at '
+                              'its copy rate (roofline.measured_stream_ceilings)',
                 'note': 'streamed bytes of all builder kernels (bench.py: builder_bytes) / HIP-event time of the whole build (second '
                         'build of the process; first_build_device_ms includes workspace allocation and kernel loading); '
                         'd^-1/2 of the columns comes from counts carried in the keys on this workload (no random reads)'},
