@@ -105,7 +105,11 @@ def one_case(rng, idx):
     terms = sum(z.detach().abs() @ W[k].detach().abs() for k, z in enumerate(zs)) + b.detach().abs()
     out_floor = max(1e-7, 8 * 6e-8 * float(terms.max()))
     close(pc[:, 0], o_re.detach(), 1e-5, 'out real', out_floor); close(pc[:, 1], o_im.detach(), 1e-5, 'out imag', out_floor)
-    close(conv.weight.grad.cpu(), W.grad, 1e-5, 'dW')
+    # dW[k] is a sum over all nodes of products of both signs, like db below: float32 accumulates it to within its
+    # backward error — a few ulps of the sum of the products' magnitudes — not of a result that cancellation made small
+    gmag = Wt[:, 0].double().abs() + Wt[:, 1].double().abs()
+    dw_floor = 8 * 6e-8 * max(float(((z.detach().real.abs() + z.detach().imag.abs()).t() @ gmag).max()) for z in zs)
+    close(conv.weight.grad.cpu(), W.grad, 1e-5, 'dW', max(1e-7, dw_floor))
     # db is a plain sum over all nodes of terms of both signs: a float32 sum is accurate relative to the sum of the
     # terms' magnitudes (backward error), not to a result that cancellation has made small
     db_err = float((conv.bias.grad.cpu().double() - b.grad).abs().max())

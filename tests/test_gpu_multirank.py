@@ -152,6 +152,15 @@ def _worker_native(rank, world, port, out_dir):
             got2 = run()                                                                   # the object is reused call after call
             same = all(torch.equal(a, b) for a, b in zip(want[0], got[0])) and torch.equal(want[1], got[1]) \
                 and torch.equal(want[2], got[2]) and torch.equal(want[1], got2[1]) and torch.equal(want[2], got2[2])
+            # the object's all-gather: every rank's vector, in rank order, on every rank
+            from magnet_amd._lib import ops
+            mine = torch.full((1000,), float(rank + 1), device=dev) + torch.arange(1000, device=dev) * 1e-3
+            everyone = torch.full((world * 1000,), float('nan'), device=dev)
+            ops.exchange_all_gather(part._exchange, mine, everyone, world)
+            ops.exchange_end(part._exchange, everyone)
+            torch.cuda.synchronize()
+            expect = torch.cat([torch.full((1000,), float(r + 1), device=dev) + torch.arange(1000, device=dev) * 1e-3 for r in range(world)])
+            same = same and torch.equal(everyone, expect)
             in_place = sum(int(g.numel() == part.n_local) for p, g in enumerate(part.give) if p != rank and g is not None)
             report[name] = {'same': bool(same), 'finite': bool(torch.isfinite(got[1]).all()), 'in_place_peers': in_place,
                             'n_halo': part.n_halo}
