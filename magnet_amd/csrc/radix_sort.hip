@@ -25,6 +25,7 @@ constexpr int kItems = 16;
 constexpr int kTile = kThreads * kItems;     // 8192 keys
 constexpr int kBins = 256;
 constexpr int kChunk = 256;                  // tiles per scan chunk
+constexpr int kXcds = 8;                     // accelerator dies of the device; workgroup i runs on die i % 8
 
 __device__ inline uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return uint32_t(k >> shift) & mask; }
 
@@ -51,6 +52,43 @@ __device__ inline uint64_t record_key(const RecordSource& g, int64_t p, float& w
     const int64_t r = dir ? j : i, c = dir ? i : j;
     if (FLAG && (r < g.row_lo || r >= g.row_hi)) atomicOr(g.err, 2);
     return (uint64_t(r) << (g.cb + 1)) | (uint64_t(c) << 1) | uint64_t(dir);
+}
+
+// The same records for a stretch that lies wholly inside list `dir`'s edges (no self-loop entries, one direction): the
+// common case of all but a few tiles.  `e0` is the list entry of this lane's first record; the ITEMS records of a
+// lane are 64 entries apart.  Same keys, weights and error flags as record_key, without its per-record case analysis.
+template <typename IdxT, bool FLAG, int ITEMS, bool WEIGHTS>
+__device__ inline void record_keys_inside(const RecordSource& g, int dir, int64_t e0, uint64_t (&key)[ITEMS], float* w) {
+    const IdxT* __restrict__ rp = static_cast<const IdxT*>(g.row[dir]) + e0;
+    const IdxT* __restrict__ cp = static_cast<const IdxT*>(g.col[dir]) + e0;
+    const float* __restrict__ wp = g.w[dir] ? g.w[dir] + e0 : nullptr;
+    IdxT a[ITEMS], b[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { a[i] = rp[i * 64]; b[i] = cp[i * 64]; }
+    const bool check_rows = g.row_lo != 0 || g.row_hi != g.n_nodes;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        int64_t ii = int64_t(a[i]), jj = int64_t(b[i]);
+        float wv = 1.0f;
+        if (WEIGHTS && wp) wv = wp[i * 64];
+        if (uint64_t(ii) >= uint64_t(g.n_nodes) || uint64_t(jj) >= uint64_t(g.n_nodes)) {
+            if (FLAG) atomicOr(g.err, 1);
+            ii = jj = g.row_lo; wv = 0.0f;
+        }
+        const int64_t r = dir ? jj : ii, c = dir ? ii : jj;
+        if (FLAG && check_rows && (r < g.row_lo || r >= g.row_hi)) atomicOr(g.err, 2);
+        key[i] = (uint64_t(r) << (g.cb + 1)) | (uint64_t(c) << 1) | uint64_t(dir);
+        if (WEIGHTS) w[i] = wv;
+    }
+}
+
+// which list a stretch of `len` records starting at record p0 lies wholly inside (its edges, not its self-loop entries):
+// 0, 1, or -1 for neither
+__device__ inline int list_of_stretch(const RecordSource& g, int64_t p0, int64_t len, int64_t& e_first) {
+    const int64_t cnt0 = g.n_in[0] + g.n_self[0];
+    if (p0 + len <= g.n_in[0]) { e_first = p0; return 0; }
+    if (p0 >= cnt0 && p0 + len <= cnt0 + g.n_in[1]) { e_first = p0 - cnt0; return 1; }
+    return -1;
 }
 
 // GEN: 0 = keys in memory, 1 / 2 = records made from int32 / int64 edge lists
@@ -83,10 +121,22 @@ __global__ void __launch_bounds__(kThreads) tile_histogram(const uint64_t* __res
             atomicAdd(&bins[digit_of(k[i].y, shift, mask)], 1u);
         }
     } else {
+        int64_t e_first = 0;
+        const int inside = (GEN != 0 && base + kTile <= n) ? list_of_stretch(gen, base, kTile, e_first) : -1;
+        if (GEN != 0 && inside >= 0) {
+            // a full tile inside one edge list (a histogram does not care which lane sees which record)
+            uint64_t k[kItems];
+            const int64_t e0 = e_first + int64_t(threadIdx.x >> 6) * (64 * kItems) + (threadIdx.x & 63);
+            if (GEN == 1) record_keys_inside<int32_t, false, kItems, false>(gen, inside, e0, k, nullptr);
+            else record_keys_inside<int64_t, false, kItems, false>(gen, inside, e0, k, nullptr);
 #pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            int64_t idx = base + i * kThreads + threadIdx.x;
-            if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
+            for (int i = 0; i < kItems; ++i) atomicAdd(&bins[digit_of(k[i], shift, mask)], 1u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) {
+                int64_t idx = base + i * kThreads + threadIdx.x;
+                if (idx < n) atomicAdd(&bins[digit_of(key_at<GEN>(keys, gen, idx), shift, mask)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -249,13 +299,20 @@ template <bool PAIRS, bool TAG, int NB, bool HI, bool FULL, int GEN>
 __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint64_t* __restrict__ kin,
                                     uint64_t* __restrict__ kout, const float* __restrict__ vin, float* __restrict__ vout,
                                     int64_t n, int shift, uint32_t mask, uint32_t my_goff, const Tag& tag,
-                                    const RecordSource& gen) {
+                                    const RecordSource& gen, int64_t tile) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t tile_base = int64_t(blockIdx.x) * kTile;
+    const int64_t tile_base = tile * kTile;
     const int64_t chunk_base = tile_base + int64_t(w) * (64 * kItems);
     uint64_t key[kItems];
     float val[PAIRS ? kItems : 1];
     uint32_t rank[kItems];
+    int64_t e_first = 0;
+    const int inside = (GEN != 0 && FULL) ? list_of_stretch(gen, tile_base, kTile, e_first) : -1;
+    if (GEN != 0 && inside >= 0) {
+        const int64_t e0 = e_first + int64_t(w) * (64 * kItems) + lane;
+        if (GEN == 1) record_keys_inside<int32_t, true, kItems, PAIRS>(gen, inside, e0, key, val);
+        else record_keys_inside<int64_t, true, kItems, PAIRS>(gen, inside, e0, key, val);
+    } else
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         int64_t idx = chunk_base + i * 64 + lane;
@@ -362,19 +419,27 @@ template <bool PAIRS, bool TAG, int NB, bool HI, int GEN>
 __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                     const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
                                                     int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag,
-                                                    const RecordSource gen) {
+                                                    const RecordSource gen, int64_t n_tiles) {
     __shared__ ScatterShared sh;
     __shared__ float svals[PAIRS ? kTile : 1];
     const int tid = threadIdx.x;
+    // Workgroups go to the eight XCDs round robin.  Each XCD takes one contiguous eighth of the tiles, so that the
+    // tiles in flight on an XCD are neighbours: their runs of one digit are neighbours in the output too, and the
+    // XCD's L2 collects spans of many KiB per digit instead of every eighth 256-byte run.
+    const int64_t per_xcd = (n_tiles + kXcds - 1) / kXcds;
+    const int64_t tile = int64_t(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (tile >= n_tiles) return;
     for (int i = tid; i < kWaves * kBins; i += kThreads) (&sh.cnt[0][0])[i] = 0;
     uint32_t my_goff = 0;
-    if (tid < kBins) my_goff = offs[int64_t(blockIdx.x) * kBins + tid];
+    if (tid < kBins) my_goff = offs[tile * kBins + tid];
     __syncthreads();
-    if (int64_t(blockIdx.x) * kTile + kTile <= n)
-        scatter_tile<PAIRS, TAG, NB, HI, true, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen);
+    if (tile * kTile + kTile <= n)
+        scatter_tile<PAIRS, TAG, NB, HI, true, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen, tile);
     else
-        scatter_tile<PAIRS, TAG, NB, HI, false, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen);
+        scatter_tile<PAIRS, TAG, NB, HI, false, GEN>(sh, svals, kin, kout, vin, vout, n, shift, mask, my_goff, tag, gen, tile);
 }
+
+inline unsigned scatter_grid(unsigned tiles) { return (tiles + kXcds - 1) / kXcds * kXcds; }
 
 template <bool PAIRS, bool TAG>
 void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint64_t* b, const float* va, float* vb, int64_t n,
@@ -384,11 +449,11 @@ void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint6
     // digits of 7 bits (42-bit keys in 6 passes) are matched with 7 ballots; every other width with 8 (the bits above
     // the digit are zero in every lane and match trivially)
     if (nb == 7) {
-        if (hi) scatter<PAIRS, TAG, 7, true, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
-        else scatter<PAIRS, TAG, 7, false, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
+        if (hi) scatter<PAIRS, TAG, 7, true, 0><<<scatter_grid(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none, int64_t(tiles));
+        else scatter<PAIRS, TAG, 7, false, 0><<<scatter_grid(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none, int64_t(tiles));
     } else {
-        if (hi) scatter<PAIRS, TAG, 8, true, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
-        else scatter<PAIRS, TAG, 8, false, 0><<<tiles, kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none);
+        if (hi) scatter<PAIRS, TAG, 8, true, 0><<<scatter_grid(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none, int64_t(tiles));
+        else scatter<PAIRS, TAG, 8, false, 0><<<scatter_grid(tiles), kThreads, 0, stream>>>(a, b, va, vb, n, shift, mask, hist, tag, none, int64_t(tiles));
     }
 }
 
@@ -396,8 +461,8 @@ void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint6
 template <bool PAIRS, int GEN>
 void launch_scatter_gen(unsigned tiles, hipStream_t stream, uint64_t* b, float* vb, int64_t n, int shift, uint32_t mask, int nb,
                         const uint32_t* hist, const RecordSource& gen) {
-    if (nb == 7) scatter<PAIRS, false, 7, false, GEN><<<tiles, kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen);
-    else scatter<PAIRS, false, 8, false, GEN><<<tiles, kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen);
+    if (nb == 7) scatter<PAIRS, false, 7, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
+    else scatter<PAIRS, false, 8, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
 }
 
 inline size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
