@@ -520,6 +520,21 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
         first_slot[u] = any ? word_pos[(base >> 6) + u] : 0u;
     }
     const uint64_t node_mask = (1ull << cb) - 1ull;
+    // d^-1/2 of the kept entries' rows and columns depends on the keys alone: all groups' lookups are issued here,
+    // together, instead of one group's after another's arithmetic
+    float d_row[kGroups], d_col[kGroups];
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+        const uint64_t k = R.k[u];
+        const bool kept = (words[u] >> lane) & 1ull;
+        d_row[u] = d_col[u] = 0.0f;
+        if (kept) {
+            const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
+            d_row[u] = dinv[int32_t((k >> (cb + 1)) & node_mask)];
+            d_col[u] = tag < kTagCap ? tag_table[tag]      // the column's record count travelled in the key
+                                     : dinv[int32_t((k >> 1) & node_mask)];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < kGroups; ++u) {
         const uint64_t word = words[u];
@@ -540,11 +555,7 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
                       int64_t(__builtin_amdgcn_mbcnt_hi(uint32_t(word >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(word), 0u)));
         if (diag) idx += int64_t(r - row_lo) + (c > r ? 1 : 0);
         if (idx >= nnz) continue;                       // caller's arrays are shorter than the count phase reported
-        float dc;
-        const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
-        if (tag < kTagCap) dc = tag_table[tag];         // the column's record count travelled in the key
-        else dc = dinv[c];
-        float a = (dinv[r] * sv) * dc;                  // (D A_s) D, hermitian.py:154
+        float a = (d_row[u] * sv) * d_col[u];           // (D A_s) D, hermitian.py:154
         float theta = two_pi_q * dv;                    // fp32 product, hermitian.py:157
         float sn, cs;
         sincosf(theta, &sn, &cs);                       // full-range accurate sincos, hermitian.py:158
