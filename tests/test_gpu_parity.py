@@ -1718,3 +1718,32 @@ def test_builder_at_tile_boundaries(e, weighted):
     L = H.hermitian_decomp_sparse(one, one + 3, n, 0.2, edge_weight=w)
     Lo = O.hermitian_decomp_sparse(one, one + 3, n, 0.2, edge_weight=w)
     _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6, what='one pair, e=%d' % e)
+
+
+@pytest.mark.parametrize('dtype', [np.int32, np.int64])
+def test_bad_endpoints_are_found_inside_full_tiles(dtype):
+    """An endpoint out of range, or an edge outside a rank's row block, in the middle of a large edge list: the records
+    of such tiles are made by the per-tile path of the first radix pass, which must flag what the per-record path flags."""
+    mh, lap, H, _, O = _mods()
+    rng = np.random.default_rng(17)
+    n, e = 5000, 100_000                                   # 200 000 records: two dozen full tiles per direction
+    row = rng.integers(0, n, e).astype(dtype); col = rng.integers(0, n, e).astype(dtype)
+    L = H.hermitian_decomp_sparse(row, col, n, 0.2)        # clean input builds, and is the oracle's matrix
+    Lo = O.hermitian_decomp_sparse(row, col, n, 0.2)
+    _assert_same_csr(L, Lo.indptr, Lo.indices, Lo.data, rel=2e-6)
+    for where, bad in ((e // 2, n), (e // 3, -1), (e - 20_000, n + 12345)):
+        for side in (row, col):
+            keep = side[where]
+            side[where] = bad
+            with pytest.raises(mh.MagnetHipError, match='endpoint'):
+                H.hermitian_decomp_sparse(row, col, n, 0.2)
+            side[where] = keep
+    # a rank's row block: every forward edge must start in the block
+    r0, r1 = 1000, 3000
+    tr, tc = torch.from_numpy(row).to(DEV), torch.from_numpy(col).to(DEV)
+    fwd = (tr >= r0) & (tr < r1); bwd = (tc >= r0) & (tc < r1)
+    ok = lap.LaplacianBlockBuild((tr[fwd], tc[fwd]), (tr[bwd], tc[bwd]), n, r0, r1)
+    assert ok.nnz > 0
+    fr = tr[fwd].clone(); fr[fr.numel() // 2] = r1 + 5     # an edge of another rank's rows, deep inside the list
+    with pytest.raises(mh.MagnetHipError, match='row block'):
+        lap.LaplacianBlockBuild((fr, tc[fwd]), (tr[bwd], tc[bwd]), n, r0, r1)
