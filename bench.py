@@ -209,7 +209,7 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges, MagneticLaplacian
     from magnet_amd.layer.sparse_magnet import ChebNet, ChebConv
     from magnet_amd.utils.hermitian import ChebBasis
-    from magnet_amd.train import node_epoch, NodeTargets
+    from magnet_amd.train import node_epoch, NodeTargets, SharedForwardEpochs
     f, K, ncls = 128, 2, 5
     gen = torch.Generator(device=dev).manual_seed(3)
     X = torch.randn(n, f, device=dev, generator=gen)
@@ -253,7 +253,7 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
         tr, va = NodeTargets(y, train), NodeTargets(y, ~train)
         run = lambda: node_epoch(net, opt, X, X, y, tr, va)
 
-    def timed(iters=5):
+    def timed(iters=5, run=run):
         for _ in range(2):
             run()
         if multi:
@@ -279,9 +279,26 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
     if multi:
         sh.cache_input_propagation = True
     ms_cached = timed()
+    shared_ms = shared_cached_ms = None
+    if not multi:
+        # the evaluation's pass through the convolutions kept for the next epoch's training step (same weights, same
+        # tensor: magnet_amd.train.SharedForwardEpochs): one forward per epoch instead of two, identical results
+        shared = SharedForwardEpochs(net, opt)
+        run_shared = lambda: shared.node_epoch(X, X, y, tr, va)
+        shared_cached_ms = timed(run=run_shared)
+        ChebConv.cache_input_propagation = False
+        shared.reset()
+        shared_ms = timed(run=run_shared)
+        shared.reset()
     ChebConv.cache_input_propagation = False       # back to the default
     kind = {'rows': ', RowShardedChebNet over per-rank built row blocks', 'cols': ', ShardedChebNet (whole CSR on every rank)'}
-    out = {'ms': ms, 'ms_with_cached_input_propagation': ms_cached, 'n_gpus': world, 'nnz': nnz, 'layout': layout if multi else 'single',
+    out = {'ms': ms, 'ms_with_cached_input_propagation': ms_cached, 'ms_with_shared_forward': shared_ms,
+           'ms_with_shared_forward_and_cached_input_propagation': shared_cached_ms,
+           'shared_forward_note': 'the evaluation forward of epoch e and the training forward of epoch e+1 run under the same '
+                                  'weights and differ only in the dropout after the convolutions: one pass through the '
+                                  'convolutions serves both (train.SharedForwardEpochs; same losses, accuracies and '
+                                  'parameters as the plain epoch, which is what `ms` times)' if shared_ms is not None else None,
+           'n_gpus': world, 'nnz': nnz, 'layout': layout if multi else 'single',
            'config': 'config 4: power-law digraph N=%d E=%d, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
                      'train fwd+bwd+Adam + eval fwd' % (n, e) + (kind[layout] if multi else '')}
     out.update(extra)

@@ -21,7 +21,7 @@ from .layer.sparse_magnet import ChebNet_Edge
 from .utils.edge_data import in_out_degree, generate_dataset_3class, link_prediction_evaluation, acc, split_cache_prefix
 from .utils.preprocess import to_edge_dataset_sparse
 from .utils.save_settings import write_log
-from .train import link_epoch, GraphedEpoch
+from .train import link_epoch, GraphedEpoch, SharedForwardEpochs
 
 
 def parse_args(argv=None):
@@ -50,6 +50,10 @@ def parse_args(argv=None):
     parser.add_argument('--splits', type=int, default=10)
     parser.add_argument('--true_degrees', action='store_true',
                         help='use real in/out degrees as features instead of the reference\'s as-written call')
+    parser.add_argument('--separate_forwards', action='store_true',
+                        help='(not in the reference) run the training and the validation forward of an epoch as two '
+                             'passes, as the reference does; by default the validation pass through the convolutions '
+                             'also serves the next training step (train.SharedForwardEpochs: same numbers)')
     parser.add_argument('--hip_graph', action='store_true',
                         help='(not in the reference) capture the epoch once and replay it as one HIP graph: the '
                              'small datasets spend their epoch in launch overhead')
@@ -109,6 +113,11 @@ def main(args):
         best_test_err, early_stopping, log_str_full = 1000.0, 0, ''
         # one epoch of reference src/Edge_sparseMagnet.py:168-199: training step, then the validation forward
         body = lambda: link_epoch(model, opt, X_real, X_img, idx['train'], y['train'], idx['validate'], y['validate'])
+        if not (args.hip_graph or args.separate_forwards):
+            # same numbers, one pass through the convolutions per epoch: the validation forward is kept for the next
+            # training step (same weights; pair gather and dropout act after the convolutions)
+            shared = SharedForwardEpochs(model, opt)
+            body = lambda: shared.link_epoch(X_real, X_img, idx['train'], y['train'], idx['validate'], y['validate'])
         if args.hip_graph:
             # the capture's warm-up epochs are real optimizer steps: rewind parameters and Adam state in place
             start = [p.detach().clone() for p in model.parameters()]

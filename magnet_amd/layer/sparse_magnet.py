@@ -744,14 +744,23 @@ class ChebNet(nn.Module):
         self.Conv = nn.Conv1d(num_filter * last_dim, label_dim, kernel_size=1)
         self.dropout = dropout
 
-    def forward(self, real, imag):
-        p = _run_trunk(self.Chebs, real, imag)
+    def trunk(self, real, imag):
+        """The convolutions and activations: row-planar [N, 2, F] output of the last one.  Nothing in it depends
+        on train / eval mode (dropout acts after it), so one trunk pass can serve an evaluation forward and the
+        training forward that follows it under the same weights (magnet_amd.train.SharedForwardEpochs)."""
+        return _run_trunk(self.Chebs, real, imag)
+
+    def head(self, p):
+        """unwind -> dropout -> Conv1d(2F, label_dim, 1) -> log_softmax of a trunk output."""
         x = p.reshape(p.size(0), -1)                   # == cat((real, imag), -1): same memory
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
         # Conv1d with kernel 1 over [1, 2F, N] is a linear map per node
         x = _HeadFn.apply(x, self.Conv.weight.squeeze(-1), self.Conv.bias)          # [1, label_dim, N]
         return F.log_softmax(x, dim=1)
+
+    def forward(self, real, imag):
+        return self.head(self.trunk(real, imag))
 
 
 class ChebNet_Edge(nn.Module):
@@ -774,13 +783,20 @@ class ChebNet_Edge(nn.Module):
         self.linear = nn.Linear(num_filter * last_dim * 2, label_dim)
         self.dropout = dropout
 
-    def forward(self, real, imag, index):
-        p = _run_trunk(self.Chebs, real, imag)
+    def trunk(self, real, imag):
+        """The convolutions and activations (independent of train / eval mode and of the query pairs)."""
+        return _run_trunk(self.Chebs, real, imag)
+
+    def head(self, p, index):
+        """pair gather -> dropout -> Linear(4F, label_dim) -> log_softmax of a trunk output."""
         x = _PairGatherFn.apply(p, index)              # == cat(real[i], real[j], imag[i], imag[j])
         if self.dropout > 0:
             x = F.dropout(x, self.dropout, training=self.training)
         x = self.linear(x)
         return F.log_softmax(x, dim=1)
+
+    def forward(self, real, imag, index):
+        return self.head(self.trunk(real, imag), index)
 
 
 class MagNetConv(nn.Module):

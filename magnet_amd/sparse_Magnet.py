@@ -22,7 +22,7 @@ import torch.optim as optim
 
 from . import data as D
 from .layer.sparse_magnet import ChebNet
-from .train import node_epoch, GraphedEpoch, NodeTargets
+from .train import node_epoch, GraphedEpoch, NodeTargets, SharedForwardEpochs
 from .utils.preprocess import geometric_dataset_sparse
 from .utils.save_settings import write_log
 
@@ -53,6 +53,10 @@ def parse_args(argv=None):
     parser.add_argument('--settings_dir', type=str, default='.',
                         help='where the saved best-setting dictionaries (syn_settings.pk, Cyclic_setting_dict.pk, '
                              'Cyclic_fill_setting_dict.pk) live; the reference opens them in the working directory')
+    parser.add_argument('--separate_forwards', action='store_true',
+                        help='(not in the reference) run the training and the validation forward of an epoch as two '
+                             'passes, as the reference does; by default the validation pass through the convolutions '
+                             'also serves the next training step (train.SharedForwardEpochs: same numbers)')
     parser.add_argument('--hip_graph', action='store_true',
                         help='(not in the reference) capture the epoch once and replay it as one HIP graph: the '
                              'small datasets spend their epoch in launch overhead')
@@ -188,6 +192,11 @@ def main(args):
         # criterion(preds[:, :, index], label[:, index]) without the per-epoch gather and index-put
         train_targets, val_targets = NodeTargets(label, train_index), NodeTargets(label, val_index)
         body = lambda: node_epoch(model, opt, X_real, X_img, label, train_targets, val_targets, criterion)
+        if not (args.hip_graph or args.separate_forwards):
+            # same numbers, one pass through the convolutions per epoch: the validation forward is kept for the next
+            # training step (same weights; dropout acts after the convolutions)
+            shared = SharedForwardEpochs(model, opt)
+            body = lambda: shared.node_epoch(X_real, X_img, label, train_targets, val_targets, criterion)
         if args.hip_graph:
             # the capture's warm-up epochs are real optimizer steps: rewind parameters and Adam state in place
             start = [p.detach().clone() for p in model.parameters()]

@@ -3,6 +3,7 @@
 
     node_epoch  — reference src/sparse_Magnet.py:143-176
     link_epoch  — reference src/Edge_sparseMagnet.py:168-199
+    SharedForwardEpochs — the same epochs, the evaluation forward shared with the next training forward
 Checkpoint writes (src/sparse_Magnet.py:188-197, src/Edge_sparseMagnet.py:210-215) are the caller's
 business and are not part of the timed epoch.
 """
@@ -78,6 +79,84 @@ def link_epoch(model, opt, X_real, X_img, train_index, y_train, val_index, y_val
         val_loss = F.nll_loss(out, y_val)
         val_acc = (out.max(dim=1)[1] == y_val).float().mean()
     return train_loss.detach(), train_acc, val_loss, val_acc
+
+
+class SharedForwardEpochs:
+    """The same epochs with ONE pass through the convolutions per epoch instead of two.
+
+    The reference's epoch is: training forward, backward, Adam step, evaluation forward (src/sparse_Magnet.py:153-176,
+    src/Edge_sparseMagnet.py:176-199).  The evaluation forward of epoch e and the training forward of epoch e + 1 run
+    under the same weights (nothing steps in between), and train / eval mode only reaches the dropout in front of the
+    last linear map: the convolutions (model.trunk) compute the same tensor in both.  So the trunk pass made for the
+    evaluation is recorded by autograd and kept; the next epoch applies the head in training mode to it (fresh dropout
+    mask, as the reference draws one) and backpropagates through the kept pass.  Every loss, accuracy and parameter is
+    what node_epoch / link_epoch give (the first epoch makes one extra trunk pass); full-batch models with K orders
+    per layer save half of their forward SpMMs.
+
+    The kept pass is used only while the parameters and the input tensors are the objects and versions it was made
+    from (optimizer steps made elsewhere, load_state_dict, in-place writes to X invalidate it); reset() drops it.
+    Memory: the saved activations of one forward stay alive between epochs (the peak — one training forward — is
+    unchanged).  Not for GraphedEpoch: the first epoch differs from the others."""
+
+    def __init__(self, model, opt):
+        self.model, self.opt = model, opt
+        self._kept = None
+
+    def reset(self):
+        self._kept = None
+
+    def _key(self, X_real, X_img):
+        ts = [X_real, X_img] + list(self.model.parameters())
+        return tuple((id(t), t._version) for t in ts)
+
+    def _trunk(self, X_real, X_img):
+        kept, self._kept = self._kept, None
+        if kept is not None and kept[0] == self._key(X_real, X_img):
+            return kept[1]
+        return self.model.trunk(X_real, X_img)
+
+    def _step(self, loss):
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+
+    def _evaluation_trunk(self, X_real, X_img):
+        self.model.eval()
+        p = self.model.trunk(X_real, X_img)              # recorded: the next epoch backpropagates through it
+        self._kept = (self._key(X_real, X_img), p, X_real, X_img)     # the inputs held: their ids stay theirs
+        return p.detach()
+
+    def node_epoch(self, X_real, X_img, label, train_index, val_index, criterion=None):
+        """Arguments and results of node_epoch."""
+        criterion = criterion or torch.nn.NLLLoss()
+        model = self.model
+        p = self._trunk(X_real, X_img)
+        model.train()
+        preds = model.head(p)
+        train_loss, train_acc = _loss_acc(preds, label, train_index, criterion)
+        del p, preds
+        self._step(train_loss)
+        p = self._evaluation_trunk(X_real, X_img)
+        with torch.no_grad():
+            val_loss, val_acc = _loss_acc(model.head(p), label, val_index, criterion)
+        return train_loss.detach(), train_acc, val_loss, val_acc
+
+    def link_epoch(self, X_real, X_img, train_index, y_train, val_index, y_val):
+        """Arguments and results of link_epoch."""
+        model = self.model
+        p = self._trunk(X_real, X_img)
+        model.train()
+        out = model.head(p, train_index)
+        train_loss = F.nll_loss(out, y_train)
+        train_acc = (out.max(dim=1)[1] == y_train).float().mean()
+        del p, out
+        self._step(train_loss)
+        p = self._evaluation_trunk(X_real, X_img)
+        with torch.no_grad():
+            out = model.head(p, val_index)
+            val_loss = F.nll_loss(out, y_val)
+            val_acc = (out.max(dim=1)[1] == y_val).float().mean()
+        return train_loss.detach(), train_acc, val_loss, val_acc
 
 
 class GraphedEpoch:

@@ -1057,6 +1057,68 @@ def test_hip_graph_epoch_replay_matches_eager():
         assert_close(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rel=1e-4)
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.5])
+def test_shared_forward_epochs_match_plain_epochs(dropout):
+    """SharedForwardEpochs (the evaluation's pass through the convolutions kept for the next training step) gives the
+    losses, accuracies and parameters of node_epoch / link_epoch — with dropout too (it acts after the convolutions,
+    and both forms draw one mask per epoch) — and a kept pass is dropped when the weights change behind its back."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd.train import node_epoch, link_epoch, SharedForwardEpochs
+    from magnet_amd.data import dsbm_cyclic
+    g = dsbm_cyclic(n_per_cluster=100, clusters=5, seed=2)
+    n = g.x.size(0)
+    L = H.hermitian_decomp_sparse_device(g.edge_index[0], g.edge_index[1], n, 0.1)
+    X = g.x.to(DEV); y = g.y[None].to(DEV)
+    tr = g.train_mask[:, 0].nonzero().squeeze(1).to(DEV); va = g.val_mask[:, 0].nonzero().squeeze(1).to(DEV)
+
+    def make(cls, **kw):
+        torch.manual_seed(5)
+        net = cls(1, H.cheb_poly_sparse(L, 2), None, num_filter=16, K=2, activation=True, layer=2, dropout=dropout, **kw).to(DEV)
+        return net, torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
+
+    def same(a, b, what):
+        assert_close(np.array(b, dtype=np.float64), np.array(a, dtype=np.float64), rel=1e-6, what=what)
+
+    # node classification, 6 epochs; after the third the weights are perturbed in place (what load_state_dict does)
+    def run_nodes(shared):
+        net, opt = make(M.ChebNet, label_dim=5)
+        ep = SharedForwardEpochs(net, opt)
+        torch.manual_seed(11)
+        stats = []
+        for i in range(6):
+            if i == 3:
+                with torch.no_grad():
+                    net.Chebs[0].weight.mul_(1.01)
+            out = ep.node_epoch(X, X, y, tr, va) if shared else node_epoch(net, opt, X, X, y, tr, va)
+            stats.append([float(t) for t in out])
+        return stats, [q.detach().cpu().numpy() for q in net.parameters()]
+    s_plain, p_plain = run_nodes(False)
+    s_shared, p_shared = run_nodes(True)
+    same(s_plain, s_shared, 'node epochs: losses and accuracies')
+    for a, b in zip(p_plain, p_shared):
+        assert_close(b, a, rel=1e-6, what='node epochs: parameters')
+
+    # link prediction on random pairs, 4 epochs
+    gen = torch.Generator().manual_seed(3)
+    pt = torch.randint(0, n, (300, 2), generator=gen).to(DEV); yt = torch.randint(0, 2, (300,), generator=gen).to(DEV)
+    pv = torch.randint(0, n, (90, 2), generator=gen).to(DEV); yv = torch.randint(0, 2, (90,), generator=gen).to(DEV)
+
+    def run_links(shared):
+        net, opt = make(M.ChebNet_Edge, label_dim=2)
+        ep = SharedForwardEpochs(net, opt)
+        torch.manual_seed(12)
+        stats = []
+        for _ in range(4):
+            out = ep.link_epoch(X, X, pt, yt, pv, yv) if shared else link_epoch(net, opt, X, X, pt, yt, pv, yv)
+            stats.append([float(t) for t in out])
+        return stats, [q.detach().cpu().numpy() for q in net.parameters()]
+    s_plain, p_plain = run_links(False)
+    s_shared, p_shared = run_links(True)
+    same(s_plain, s_shared, 'link epochs: losses and accuracies')
+    for a, b in zip(p_plain, p_shared):
+        assert_close(b, a, rel=1e-6, what='link epochs: parameters')
+
+
 def test_spmm_full_size_properties():
     """Config-5 size (10M nodes / 200M edges / 256 complex features, ~70 GB): properties that need
     no oracle run.  Bitwise determinism; exact homogeneity under a power-of-two scale; a real

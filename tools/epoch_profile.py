@@ -1,6 +1,7 @@
 """Config-4 training epochs (2-layer ChebNet, 128 filters, K=2, on a 2M-node / 40M-edge power-law digraph) and nothing else,
 for `rocprofv3 --kernel-trace --stats -- python3 tools/epoch_profile.py`: the per-kernel table then shows where an epoch's
-time goes.  --cached keeps the first layer's propagated input across forwards."""
+time goes.  --cached keeps the first layer's propagated input across forwards; --shared runs the epochs through
+train.SharedForwardEpochs (the evaluation's pass through the convolutions kept for the next training step)."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +13,7 @@ def main():
     p.add_argument('--edges', type=int, default=40_000_000)
     p.add_argument('--epochs', type=int, default=5)
     p.add_argument('--cached', action='store_true')
+    p.add_argument('--shared', action='store_true')
     p.add_argument('--gather-loss', action='store_true', help='the reference form of the loss: criterion(preds[:, :, idx], label[:, idx])')
     p.add_argument('--layout', choices=['single', 'cols', 'rows'], default='single',
                    help='cols / rows: the multi-GPU networks (ShardedChebNet / RowShardedChebNet) with one rank')
@@ -19,7 +21,7 @@ def main():
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges
     from magnet_amd.layer.sparse_magnet import ChebNet, ChebConv
     from magnet_amd.utils.hermitian import ChebBasis
-    from magnet_amd.train import node_epoch, NodeTargets
+    from magnet_amd.train import node_epoch, NodeTargets, SharedForwardEpochs
     dev = torch.device('cuda', 0)
     f, K, ncls, n = 128, 2, 5, a.nodes
     src, dst = powerlaw_edges(n, a.edges, 42, device=dev)
@@ -38,6 +40,9 @@ def main():
         tr, va = NodeTargets(y, tr), NodeTargets(y, va)
     ChebConv.cache_input_propagation = a.cached
     run = lambda: node_epoch(net, opt, X, X, y, tr, va)
+    if a.shared:
+        shared = SharedForwardEpochs(net, opt)
+        run = lambda: shared.node_epoch(X, X, y, tr, va)
     if a.layout != 'single':
         import torch.distributed as dist
         from magnet_amd import dist as D
@@ -57,7 +62,7 @@ def main():
     for _ in range(a.epochs):
         run()
     torch.cuda.synchronize()
-    print('epoch %.2f ms (nnz %d, cached=%s, layout=%s)' % ((time.perf_counter() - t0) / a.epochs * 1e3, lap.nnz, a.cached, a.layout))
+    print('epoch %.2f ms (nnz %d, cached=%s, shared=%s, layout=%s)' % ((time.perf_counter() - t0) / a.epochs * 1e3, lap.nnz, a.cached, a.shared, a.layout))
 
 
 if __name__ == '__main__':
