@@ -280,7 +280,14 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
         sh.cache_input_propagation = True
     ms_cached = timed()
     shared_ms = shared_cached_ms = None
-    if not multi:
+    if multi:
+        sh.shared_forward = True                   # the same over the ranks (ShardedChebNet.shared_forward)
+        shared_cached_ms = timed()
+        sh.cache_input_propagation = False
+        sh._kept_pass = sh._input_cache = None
+        shared_ms = timed()
+        sh.shared_forward, sh._kept_pass = False, None
+    else:
         # the evaluation's pass through the convolutions kept for the next epoch's training step (same weights, same
         # tensor: magnet_amd.train.SharedForwardEpochs): one forward per epoch instead of two, identical results
         shared = SharedForwardEpochs(net, opt)

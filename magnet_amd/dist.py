@@ -940,6 +940,13 @@ class ShardedChebNet:
     # layer then costs one row-local GEMM per forward, no SpMM and no communication.
     cache_input_propagation = False
 
+    # The evaluation forward of an epoch and the training forward of the next run under the same weights and differ only
+    # in the dropout of the head.  With this switch on, epoch() records the evaluation's pass through the convolutions and
+    # the next call backpropagates through it: one pass (and one set of exchanges) per epoch instead of two, same losses
+    # and parameters (magnet_amd.train.SharedForwardEpochs is the single-GPU form).
+    shared_forward = False
+    _kept_pass = None
+
     def __init__(self, net, operator, n, rank, world, group=None):
         from .layer.sparse_magnet import ChebConv, complex_relu_layer
         self.net, self.op, self.n, self.rank, self.world, self.group = net, operator, n, rank, world, group
@@ -1007,8 +1014,11 @@ class ShardedChebNet:
 
     def forward(self, x_rows):
         """-> log-probabilities [1, label_dim, rows_me] of the rank's nodes."""
+        return self.head(self.trunk(x_rows))
+
+    def head(self, p):
+        """Row-local tail of the network on a trunk output: unwind, dropout, class scores, log-softmax."""
         import torch.nn.functional as F
-        p = self.trunk(x_rows)
         x = p.reshape(p.size(0), -1)
         if self.net.dropout > 0:
             x = F.dropout(x, self.net.dropout, training=self.net.training)
@@ -1034,17 +1044,31 @@ class ShardedChebNet:
             if isinstance(idx, NodeTargets):
                 return idx.loss(preds, reduction='sum')
             return F.nll_loss(preds[:, :, idx], label_rows[:, idx], reduction='sum')
+        def state():
+            return tuple((id(t), t._version) for t in [x_rows] + list(self.net.parameters()))
+        kept, self._kept_pass = self._kept_pass, None
         self.net.train()
-        preds = self.forward(x_rows)
+        # a pass through the convolutions kept by the evaluation of the epoch before (shared_forward): same weights,
+        # same input, and nothing in the trunk depends on train / eval mode.  Versions advance alike on every rank,
+        # so all ranks take the same branch.
+        p = kept[1] if (kept is not None and kept[0] == state()) else self.trunk(x_rows)
+        preds = self.head(p)
         loss = nll_sum(preds, train_rows) / n_train
+        del p, preds, kept
         opt.zero_grad()
         loss.backward()
         self.all_reduce_grads()
         opt.step()
         self.net.eval()
-        with torch.no_grad():
-            preds = self.forward(x_rows)
-            vloss = nll_sum(preds, val_rows) / n_val
+        if self.shared_forward:
+            p = self.trunk(x_rows)                           # recorded: the next epoch backpropagates through it
+            self._kept_pass = (state(), p, x_rows)
+            with torch.no_grad():
+                vloss = nll_sum(self.head(p.detach()), val_rows) / n_val
+        else:
+            with torch.no_grad():
+                preds = self.forward(x_rows)
+                vloss = nll_sum(preds, val_rows) / n_val
         stats = torch.stack([loss.detach(), vloss])
         if self.world > 1:
             all_reduce(stats, group=self.group)

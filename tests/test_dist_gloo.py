@@ -189,7 +189,7 @@ def test_column_bounds():
     assert b[0] == 0 and b[-1] == 5 and all(x <= y for x, y in zip(b, b[1:]))
 
 
-def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False):
+def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False, shared=False, epochs=2):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -224,12 +224,13 @@ def _worker_train(rank, world, port, out_dir, layer, cached=False, rows=False):
         else:
             sh = D.ShardedChebNet(net, op, n, rank, world)
         sh.cache_input_propagation = cached
+        sh.shared_forward = shared
         r0, r1 = sh.r0, sh.r1
         xp = torch.stack([X[r0:r1], X[r0:r1]], dim=1)
         opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4)
         tr_rows = train[r0:r1].nonzero().squeeze(1); va_rows = (~train[r0:r1]).nonzero().squeeze(1)
         losses = []
-        for _ in range(2):
+        for _ in range(epochs):
             tl, vl = sh.epoch(opt, xp, y[:, r0:r1], tr_rows, va_rows, int(train.sum()), int((~train).sum()))
             losses.append((tl.item(), vl.item()))
         torch.save({'losses': losses, 'state': {k: v.clone() for k, v in net.state_dict().items()}},
@@ -271,6 +272,22 @@ def test_sharded_chebnet_training_matches_single_process(world, layer, cached, r
             assert abs(a - c) <= 5e-5 * abs(c) and abs(b - d) <= 5e-5 * abs(d)
         for k in state:
             assert float((o['state'][k] - state[k].detach()).abs().max()) <= 5e-5 * float(state[k].detach().abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize('world,layer,cached,rows', [(2, 2, False, False), (2, 2, True, True), (3, 2, False, True)])
+def test_sharded_epochs_with_shared_forward_match_plain_epochs(world, layer, cached, rows, tmp_path):
+    """shared_forward (the evaluation's pass through the convolutions kept for the next training step) gives the
+    losses and parameters of the plain sharded epochs, over three epochs, in both layouts."""
+    plain, shared = os.path.join(str(tmp_path), 'plain'), os.path.join(str(tmp_path), 'shared')
+    os.makedirs(plain); os.makedirs(shared)
+    mp.spawn(_worker_train, args=(world, _free_port(), plain, layer, cached, rows, False, 3), nprocs=world, join=True)
+    mp.spawn(_worker_train, args=(world, _free_port(), shared, layer, cached, rows, True, 3), nprocs=world, join=True)
+    for r in range(world):
+        a = torch.load(os.path.join(plain, 't%d.pt' % r)); b = torch.load(os.path.join(shared, 't%d.pt' % r))
+        for (x0, y0), (x1, y1) in zip(a['losses'], b['losses']):
+            assert abs(x0 - x1) <= 1e-6 * abs(x0) and abs(y0 - y1) <= 1e-6 * abs(y0)
+        for k in a['state']:
+            assert float((a['state'][k] - b['state'][k]).abs().max()) <= 1e-6 * float(a['state'][k].abs().max()) + 1e-7, k
 
 
 def _free_port():

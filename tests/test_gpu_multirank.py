@@ -346,6 +346,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     for lay in ('rows', 'cols'):
         e = ep['layouts'][lay]
         assert e['ms'] > 0 and e['ms_with_cached_input_propagation'] > 0 and e['layout'] == lay, e
+        assert e['ms_with_shared_forward'] > 0 and e['ms_with_shared_forward_and_cached_input_propagation'] > 0, e
     assert 'RowShardedChebNet' in ep['layouts']['rows']['config'] and ep['layouts']['rows']['block_build_ms_rank0'] > 0
     assert ep['layouts']['rows']['nnz'] == ep['layouts']['cols']['nnz']
     assert ep['ms'] == min(ep['layouts'][l]['ms'] for l in ep['layouts'])
