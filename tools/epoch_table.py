@@ -29,15 +29,17 @@ def short(name):
     return n[:100]
 
 
-def main(path):
+def main(path, packs_per_epoch=2, marker='pack_kernel'):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    packs = [i for i, r in enumerate(rows) if 'pack_kernel' in r['Kernel_Name']]
-    # an epoch packs the input twice (training forward, evaluation forward): the last epoch starts at the
-    # fourth pack from the end and ends before the second from the end
-    if len(packs) < 4:
+    packs = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+    # an epoch packs the input twice (training forward, evaluation forward; once with the shared forward of
+    # tools/epoch_profile.py --shared: pass 1 as the second argument; when the first layer's orders are kept nothing is
+    # packed: pass a kernel that runs once per epoch as the third argument, e.g. nll_loss2d_backward — the window then
+    # runs from one training backward to the next, which is one epoch's launches all the same): the last-but-one epoch is cut out
+    if len(packs) < 2 * packs_per_epoch:
         raise SystemExit('the trace holds fewer than two epochs')
-    win = rows[packs[-4]:packs[-2]]
+    win = rows[packs[-2 * packs_per_epoch]:packs[-packs_per_epoch]]
     agg = OrderedDict()
     for r in win:
         a = agg.setdefault(short(r['Kernel_Name']), [0, 0.0])
@@ -58,4 +60,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2, sys.argv[3] if len(sys.argv) > 3 else 'pack_kernel')
