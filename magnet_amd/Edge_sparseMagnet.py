@@ -144,6 +144,7 @@ def main(args):
                 torch.save(model.state_dict(), log_path + '/model' + str(i) + '.t7')
             else:
                 early_stopping += 1
+        body = shared = None                           # the kept pass (saved activations of one forward) goes with them
         write_log(vars(args), log_path)
 
         def outputs(path):

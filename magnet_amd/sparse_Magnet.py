@@ -226,6 +226,7 @@ def main(args):
             if early_stopping > 500 or epoch == (args.epochs - 1):
                 torch.save(model.state_dict(), log_path + '/model_latest' + str(split) + '.t7')
                 break
+        body = shared = None                           # the kept pass (saved activations of one forward) goes with them
         write_log(vars(args), log_path)
 
         def evaluate(path):
