@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from magnet_amd import data as D                                               # noqa: E402
 from magnet_amd.layer.sparse_magnet import ChebNet                              # noqa: E402
 from magnet_amd.utils.hermitian import hermitian_decomp_sparse_device, cheb_poly_sparse   # noqa: E402
-from magnet_amd.train import node_epoch, GraphedEpoch                           # noqa: E402
+from magnet_amd.train import node_epoch, GraphedEpoch, SharedForwardEpochs      # noqa: E402
 from magnet_amd.sparse_Magnet import sparse_mx_to_torch_sparse_tensor          # noqa: E402
 
 dev = 'cuda'
@@ -57,6 +57,9 @@ def run(name, g, q, K, Fh, layer, iters=200):
     net = ChebNet(X.size(1), cheb_poly_sparse(L, K), None, num_filter=Fh, K=K, label_dim=ncls, activation=True, layer=layer).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True)
     eager = timeit(lambda: node_epoch(net, opt, X, X, y, tr, va), iters)
+    sh = SharedForwardEpochs(net, opt)
+    shared = timeit(lambda: sh.node_epoch(X, X, y, tr, va), iters)
+    sh.reset()
     graphed = GraphedEpoch(lambda: node_epoch(net, opt, X, X, y, tr, va))
     gms = timeit(graphed, iters)
     # reference formulation on the same GPU
@@ -74,8 +77,8 @@ def run(name, g, q, K, Fh, layer, iters=200):
             reference_formulation(state, Lr, Li, X, layer)
     ref = timeit(ref_epoch, max(iters // 4, 10))
     print(json.dumps(dict(config=name, nodes=n, edges=int(g.edge_index.size(1)), nnz=L.nnz, K=K, filters=Fh,
-                          epoch_ms_eager=round(eager, 3), epoch_ms_hipgraph=round(gms, 3),
-                          epoch_ms_reference_formulation_same_gpu=round(ref, 3),
+                          epoch_ms_eager=round(eager, 3), epoch_ms_eager_shared_forward=round(shared, 3),
+                          epoch_ms_hipgraph=round(gms, 3), epoch_ms_reference_formulation_same_gpu=round(ref, 3),
                           nnz_T=[int(t._nnz()) for t in Lr])), flush=True)
 
 
@@ -98,6 +101,9 @@ def run_link(name, case, iters=200):
     net = ChebNet_Edge(2, cheb_poly_sparse(L, K), None, num_filter=16, K=K, label_dim=2, activation=True, layer=2, dropout=0.0).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True)
     eager = timeit(lambda: link_epoch(net, opt, X, X, tp, tl, vp, vl), iters)
+    sh = SharedForwardEpochs(net, opt)
+    shared = timeit(lambda: sh.link_epoch(X, X, tp, tl, vp, vl), iters)
+    sh.reset()
     gms = timeit(GraphedEpoch(lambda: link_epoch(net, opt, X, X, tp, tl, vp, vl)), iters)
     Ts = list(cheb_poly_sparse(L, K))
     Lr = [sparse_mx_to_torch_sparse_tensor(m.real).to(dev) for m in Ts]
@@ -126,7 +132,8 @@ def run_link(name, case, iters=200):
             ref_forward(vp)
     ref = timeit(ref_epoch, max(iters // 4, 10))
     print(json.dumps(dict(config=name, nodes=size, edges=int(edges.size(1)), nnz=L.nnz, K=K, filters=16, train_pairs=int(tp.size(0)),
-                          epoch_ms_eager=round(eager, 3), epoch_ms_hipgraph=round(gms, 3),
+                          epoch_ms_eager=round(eager, 3), epoch_ms_eager_shared_forward=round(shared, 3),
+                          epoch_ms_hipgraph=round(gms, 3),
                           epoch_ms_reference_formulation_same_gpu=round(ref, 3), nnz_T=[int(m._nnz()) for m in Lr])), flush=True)
 
 
