@@ -1,0 +1,420 @@
+// Every entry point of include/magnet_hip.h (but mh_exchange_*, which abi_client covers) called from plain C++ on seeded
+// graphs, each result checked on the host: the whole-graph builder against a restatement of the reference's definition
+// (src/utils/hermitian.py:136-168) in double precision, everything else against the library's other entry points or a
+// host loop.  No torch, no Python.  Built by the Makefile and run by tests/test_gpu_parity.py; built a second time with
+// the host side under AddressSanitizer by tools/host_asan.sh (the host code of the library: workspace carving, plans,
+// two-phase calls).
+//
+//   abi_sweep            -> all cases, prints "sweep ok"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/magnet_hip.h"
+
+static int g_fail = 0;
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); exit(2); } } while (0)
+#define MH_CALL(x) do { int rc_ = (x); if (rc_ != MH_OK) { fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #x, rc_, mh_last_error()); exit(3); } } while (0)
+#define EXPECT(c, ...) do { if (!(c)) { fprintf(stderr, "%s:%d FAILED %s: ", __FILE__, __LINE__, #c); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); if (++g_fail > 20) exit(4); } } while (0)
+
+template <class T>
+struct Dev {
+    T* p = nullptr;
+    size_t n = 0;
+    explicit Dev(size_t count = 0) { resize(count); }
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+    ~Dev() { if (p) (void)hipFree(p); }
+    void resize(size_t count) {
+        if (p) HIP_OK(hipFree(p));
+        p = nullptr; n = count;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    }
+    void put(const std::vector<T>& h) { if (h.size() > n) resize(h.size()); if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    std::vector<T> get(size_t count) const { std::vector<T> h(count); if (count) HIP_OK(hipMemcpy(h.data(), p, count * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+    std::vector<T> get() const { return get(n); }
+};
+
+struct Rng {                                      // splitmix64
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() { uint64_t z = (s += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+    double uni() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+struct Csr { std::vector<int32_t> rp, ci; std::vector<float> val; };
+
+// The reference's definition in double precision (hermitian.py:136-168 with norm = laplacian = True): duplicate edges
+// summed (:139-141), self-loops added when gcn_appr (:144-145), s = (w_ij + w_ji) / 2 (:147), d = column sums of s with
+// 0 -> 1 (:150-152), entries only where w_ij != w_ji (:157-158: exact zeros of A - A.T are not stored),
+// value -(2/lam) cis(fl32(fl32(2 pi q) delta)) d_i^-1/2 s d_j^-1/2 (:153-154,:164,:167), diagonal 2/lam - 1 unless lam = 2.
+static Csr reference_laplacian(const std::vector<int32_t>& src, const std::vector<int32_t>& dst, const std::vector<float>& w,
+                               int32_t n, double q, double lam, bool gcn, std::vector<double>* dinv_out) {
+    const size_t e = src.size();
+    std::vector<std::pair<uint64_t, double>> rec(e);
+    for (size_t i = 0; i < e; ++i) rec[i] = {uint64_t(src[i]) * uint64_t(n) + uint64_t(dst[i]), w.empty() ? 1.0 : double(w[i])};
+    std::stable_sort(rec.begin(), rec.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    std::vector<uint64_t> key; std::vector<double> wt;
+    for (size_t i = 0; i < e; ++i) {
+        if (!key.empty() && key.back() == rec[i].first) wt.back() += rec[i].second;
+        else { key.push_back(rec[i].first); wt.push_back(rec[i].second); }
+    }
+    auto weight_of = [&](uint64_t k, bool* found) {
+        auto it = std::lower_bound(key.begin(), key.end(), k);
+        *found = it != key.end() && *it == k;
+        return *found ? wt[size_t(it - key.begin())] : 0.0;
+    };
+    std::vector<double> d(size_t(n), gcn ? 1.0 : 0.0);
+    for (size_t u = 0; u < key.size(); ++u) {
+        const int32_t i = int32_t(key[u] / uint64_t(n)), j = int32_t(key[u] % uint64_t(n));
+        d[size_t(i)] += 0.5 * wt[u]; d[size_t(j)] += 0.5 * wt[u];
+    }
+    std::vector<double> dinv(static_cast<size_t>(n));
+    for (int32_t i = 0; i < n; ++i) dinv[size_t(i)] = 1.0 / std::sqrt(d[size_t(i)] == 0.0 ? 1.0 : d[size_t(i)]);
+    if (dinv_out) *dinv_out = dinv;
+    struct Ent { int32_t r, c; double re, im; };
+    std::vector<Ent> ents;
+    const float two_pi_q = float(2.0 * M_PI * q);
+    auto emit = [&](int32_t i, int32_t j, double wij, double wji) {
+        const double delta = wij - wji, s = 0.5 * (wij + wji);
+        if (delta == 0.0 || s == 0.0) return;
+        const float theta = two_pi_q * float(delta);
+        const double m = -(2.0 / lam) * (dinv[size_t(i)] * s) * dinv[size_t(j)];
+        ents.push_back({i, j, m * std::cos(double(theta)), m * std::sin(double(theta))});
+    };
+    for (size_t u = 0; u < key.size(); ++u) {
+        const int32_t i = int32_t(key[u] / uint64_t(n)), j = int32_t(key[u] % uint64_t(n));
+        if (i == j) continue;
+        bool found;
+        const double wji = weight_of(uint64_t(j) * uint64_t(n) + uint64_t(i), &found);
+        emit(i, j, wt[u], wji);
+        if (!found) emit(j, i, 0.0, wt[u]);
+    }
+    if (lam != 2.0)
+        for (int32_t i = 0; i < n; ++i) ents.push_back({i, i, 2.0 / lam - 1.0, 0.0});
+    std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+    Csr out;
+    out.rp.assign(size_t(n) + 1, 0);
+    for (const Ent& t : ents) { out.rp[size_t(t.r) + 1]++; out.ci.push_back(t.c); out.val.push_back(float(t.re)); out.val.push_back(float(t.im)); }
+    for (int32_t i = 0; i < n; ++i) out.rp[size_t(i) + 1] += out.rp[size_t(i)];
+    return out;
+}
+
+static double max_abs(const std::vector<float>& a) { double m = 0; for (float v : a) m = std::max(m, double(std::fabs(v))); return m; }
+static double max_diff(const std::vector<float>& a, const std::vector<float>& b) {
+    if (a.size() != b.size()) return 1e300;
+    double m = 0; for (size_t i = 0; i < a.size(); ++i) m = std::max(m, double(std::fabs(a[i] - b[i]))); return m;
+}
+
+struct DevCsr { Dev<int32_t> rp, ci; Dev<float> val; int64_t nnz = 0; int32_t n = 0; };
+
+static void build_whole(const Dev<int32_t>& src, const Dev<int32_t>& dst, const float* w, int64_t e, int32_t n, double q, double lam,
+                        int gcn, DevCsr* L, Dev<float>* dinv) {
+    const size_t ws_bytes = mh_lap_workspace_bytes(e, n, w != nullptr, gcn);
+    Dev<unsigned char> ws(ws_bytes);
+    L->n = n; L->rp.resize(size_t(n) + 1);
+    MH_CALL(mh_lap_build_count(src.p, dst.p, 0, w, e, n, lam, gcn, ws.p, ws_bytes, L->rp.p, &L->nnz, nullptr));
+    L->ci.resize(size_t(L->nnz)); L->val.resize(size_t(L->nnz) * 2); dinv->resize(size_t(n));
+    MH_CALL(mh_lap_build_fill(e, n, q, lam, w != nullptr, gcn, ws.p, ws_bytes, L->nnz, L->ci.p, L->val.p, dinv->p, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+}
+
+struct Plan { Dev<int32_t> buf; int32_t n_long = 0, n_chunks = 0, chunk = 512; Dev<float> scratch; size_t scratch_bytes = 0; };
+
+static void make_plan(const DevCsr& L, int32_t F, Plan* P) {
+    Dev<int32_t> counters(2);
+    MH_CALL(mh_cspmm_plan_count(L.rp.p, L.n, P->chunk, counters.p, &P->n_long, &P->n_chunks, nullptr));
+    if (P->n_long == 0) return;
+    P->buf.resize(mh_cspmm_plan_ints(P->n_long, P->n_chunks));
+    MH_CALL(mh_cspmm_plan_fill(L.rp.p, L.n, P->chunk, P->n_long, P->n_chunks, P->buf.p, nullptr));
+    P->scratch.resize(size_t(P->n_chunks) * 2 * size_t(F));
+    P->scratch_bytes = P->scratch.n * sizeof(float);
+}
+
+static void run_case(const char* name, int32_t n, int64_t e, int32_t F, double q, double lam, bool weighted, int gcn, uint64_t seed) {
+    fprintf(stderr, "case %s: n=%d e=%lld F=%d q=%g lam=%g weighted=%d gcn=%d\n", name, n, (long long)e, F, q, lam, int(weighted), gcn);
+    Rng rng(seed);
+    // ---- graph: the library's power-law generator, duplicates / self-loops / reciprocal pairs as they come
+    Dev<int32_t> src{size_t(e)}, dst{size_t(e)};
+    MH_CALL(mh_powerlaw_edges(n, e, seed, 0, src.p, dst.p, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<int32_t> hs = src.get(), hd = dst.get();
+    for (int64_t i = 0; i < e; ++i) EXPECT(hs[size_t(i)] >= 0 && hs[size_t(i)] < n && hd[size_t(i)] >= 0 && hd[size_t(i)] < n, "edge %lld out of range", (long long)i);
+    for (int64_t i = 0; i + 1 < e; i += 5) { hs[size_t(i) + 1] = hd[size_t(i)]; hd[size_t(i) + 1] = hs[size_t(i)]; }   // reciprocal pairs on purpose
+    src.put(hs); dst.put(hd);
+    std::vector<float> hw;
+    Dev<float> w;
+    if (weighted) { hw.resize(size_t(e)); for (auto& v : hw) v = float(1 + rng.next() % 7); w.put(hw); }
+
+    // ---- whole-graph build against the definition
+    DevCsr L; Dev<float> dinv;
+    build_whole(src, dst, weighted ? w.p : nullptr, e, n, q, lam, gcn, &L, &dinv);
+    std::vector<double> ref_dinv;
+    Csr ref = reference_laplacian(hs, hd, hw, n, q, lam, gcn != 0, &ref_dinv);
+    std::vector<int32_t> rp = L.rp.get(), ci = L.ci.get(size_t(L.nnz));
+    std::vector<float> val = L.val.get(size_t(L.nnz) * 2), hdinv = dinv.get();
+    EXPECT(rp == ref.rp, "row_ptr differs from the definition (nnz %lld vs %zu)", (long long)L.nnz, ref.ci.size());
+    EXPECT(ci == ref.ci, "col_idx differs from the definition");
+    if (ci == ref.ci) EXPECT(max_diff(val, ref.val) <= 1e-5 * max_abs(ref.val) + 1e-9, "values: %g of %g", max_diff(val, ref.val), max_abs(ref.val));
+    for (int32_t i = 0; i < n; ++i) EXPECT(std::fabs(double(hdinv[size_t(i)]) - ref_dinv[size_t(i)]) <= 1e-6 * ref_dinv[size_t(i)], "dinv[%d]", i);
+
+    // ---- row blocks of a three-way partition, stacked = the whole CSR bit for bit (not with gcn_appr: there the caller
+    //      appends the self-loops, which the Python side does not do either)
+    const int world = 3;
+    const int32_t bounds[world + 1] = {0, n / 5, n / 2, n};
+    if (!gcn) {
+        std::vector<int32_t> st_rp{0}, st_ci; std::vector<float> st_val, st_dinv(static_cast<size_t>(n));
+        struct Blk { Dev<unsigned char> ws; size_t ws_bytes; int64_t nf, nb, nnz; Dev<int32_t> rpb; };
+        std::vector<Blk*> blks;
+        for (int p = 0; p < world; ++p) {
+            const int32_t lo = bounds[p], hi = bounds[p + 1];
+            std::vector<int32_t> fr, fc, br, bc; std::vector<float> fw, bw;
+            for (int64_t i = 0; i < e; ++i) {
+                if (hs[size_t(i)] >= lo && hs[size_t(i)] < hi) { fr.push_back(hs[size_t(i)]); fc.push_back(hd[size_t(i)]); if (weighted) fw.push_back(hw[size_t(i)]); }
+                if (hd[size_t(i)] >= lo && hd[size_t(i)] < hi) { br.push_back(hs[size_t(i)]); bc.push_back(hd[size_t(i)]); if (weighted) bw.push_back(hw[size_t(i)]); }
+            }
+            Dev<int32_t> dfr, dfc, dbr, dbc; Dev<float> dfw, dbw;
+            dfr.put(fr); dfc.put(fc); dbr.put(br); dbc.put(bc); dfw.put(fw); dbw.put(bw);
+            Blk* b = new Blk();
+            b->nf = int64_t(fr.size()); b->nb = int64_t(br.size());
+            b->ws_bytes = mh_lap_block_workspace_bytes(b->nf, b->nb, n, weighted);
+            b->ws.resize(b->ws_bytes); b->rpb.resize(size_t(hi - lo) + 1);
+            Dev<float> dblk{size_t(hi - lo)};
+            MH_CALL(mh_lap_block_count(dfr.p, dfc.p, weighted ? dfw.p : nullptr, b->nf, dbr.p, dbc.p, weighted ? dbw.p : nullptr, b->nb, 0,
+                                       weighted, n, lo, hi, lam, b->ws.p, b->ws_bytes, b->rpb.p, dblk.p, &b->nnz, nullptr));
+            std::vector<float> piece = dblk.get();
+            std::copy(piece.begin(), piece.end(), st_dinv.begin() + lo);
+            blks.push_back(b);
+        }
+        EXPECT(st_dinv == hdinv, "d^-1/2 of the blocks differs from the whole-graph build's");
+        Dev<float> dfull; dfull.put(st_dinv);
+        for (int p = 0; p < world; ++p) {
+            Blk* b = blks[size_t(p)];
+            const int32_t lo = bounds[p], hi = bounds[p + 1];
+            Dev<int32_t> bci{size_t(b->nnz)}; Dev<float> bval{size_t(b->nnz) * 2};
+            MH_CALL(mh_lap_block_fill(b->nf, b->nb, n, lo, hi, q, lam, weighted, b->ws.p, b->ws_bytes, b->nnz, dfull.p, bci.p, bval.p, nullptr));
+            HIP_OK(hipDeviceSynchronize());
+            std::vector<int32_t> r = b->rpb.get(), c = bci.get(size_t(b->nnz)); std::vector<float> v = bval.get(size_t(b->nnz) * 2);
+            const int32_t base = st_rp.back();
+            for (size_t i = 1; i < r.size(); ++i) st_rp.push_back(base + r[i]);
+            st_ci.insert(st_ci.end(), c.begin(), c.end()); st_val.insert(st_val.end(), v.begin(), v.end());
+            // halo plan of this block
+            const size_t hw_bytes = mh_halo_plan_workspace_bytes(n);
+            Dev<unsigned char> hws(hw_bytes); Dev<int32_t> dbounds; dbounds.put(std::vector<int32_t>(bounds, bounds + world + 1));
+            int64_t n_halo = -1;
+            MH_CALL(mh_halo_plan_count(bci.p, b->nnz, n, lo, hi, hws.p, hw_bytes, &n_halo, nullptr));
+            Dev<int32_t> hid{size_t(n_halo)}, pptr{size_t(world) + 1}, cl{size_t(b->nnz)};
+            MH_CALL(mh_halo_plan_fill(bci.p, b->nnz, n, lo, hi, dbounds.p, world, hws.p, hw_bytes, n_halo, hid.p, pptr.p, cl.p, nullptr));
+            HIP_OK(hipDeviceSynchronize());
+            std::vector<int32_t> ids = hid.get(size_t(n_halo)), pp = pptr.get(), loc = cl.get(size_t(b->nnz));
+            for (size_t i = 0; i < ids.size(); ++i) {
+                EXPECT(ids[i] < lo || ids[i] >= hi, "halo id %d is an own column", ids[i]);
+                if (i) EXPECT(ids[i - 1] < ids[i], "halo ids not ascending");
+            }
+            EXPECT(pp[0] == 0 && pp[size_t(world)] == int32_t(n_halo) && pp[size_t(p) + 1] == pp[size_t(p)], "peer_ptr ends / own slice");
+            for (int o = 0; o < world; ++o)
+                for (int32_t k = pp[size_t(o)]; k < pp[size_t(o) + 1]; ++k) EXPECT(ids[size_t(k)] >= bounds[o] && ids[size_t(k)] < bounds[o + 1], "halo id outside its owner's rows");
+            for (size_t i = 0; i < loc.size(); ++i) {
+                const int32_t g = loc[i] < hi - lo ? lo + loc[i] : ids[size_t(loc[i] - (hi - lo))];
+                EXPECT(g == c[i], "col_local[%zu] maps to %d, column is %d", i, g, c[i]);
+            }
+            delete b;
+        }
+        EXPECT(st_rp == rp && st_ci == ci, "stacked row blocks differ from the whole CSR in structure");
+        EXPECT(st_val == val, "stacked row blocks differ from the whole CSR in value bits");
+    }
+
+    // ---- one propagation order through the three SpMM entry points, with every epilogue
+    const size_t NF = size_t(n) * 2 * size_t(F);
+    std::vector<float> hx(NF), hz(NF), hb(static_cast<size_t>(F));
+    for (auto& v : hx) v = float(rng.uni() * 2 - 1);
+    for (auto& v : hz) v = float(rng.uni() * 2 - 1);
+    for (auto& v : hb) v = float(rng.uni() - 0.5);
+    Dev<float> X, Z, B, Y0{NF}, Y1{NF}, Y2{NF};
+    X.put(hx); Z.put(hz); B.put(hb);
+    Dev<uint8_t> M0{size_t(n) * size_t(F)}, M1{size_t(n) * size_t(F)};
+    Plan P; make_plan(L, F, &P);
+    const int64_t ld = 2 * F, im = F;
+    for (int variant = 0; variant < 3; ++variant) {
+        const float alpha = variant == 0 ? 1.0f : 2.0f;
+        const float* z1 = variant >= 1 ? Z.p : nullptr; const float b1 = variant >= 1 ? -1.0f : 0.0f;
+        const float* bias = variant == 2 ? B.p : nullptr; const int relu = variant == 2;
+        MH_CALL(mh_cspmm(L.rp.p, L.ci.p, L.val.p, n, X.p, ld, im, Y0.p, ld, im, alpha, z1, ld, im, b1, nullptr, 0, 0, 0.f, bias, relu, relu ? M0.p : nullptr, F, nullptr));
+        MH_CALL(mh_cspmm_planned(L.rp.p, L.ci.p, L.val.p, n, X.p, ld, im, Y1.p, ld, im, alpha, z1, ld, im, b1, nullptr, 0, 0, 0.f, bias, relu, relu ? M1.p : nullptr, F,
+                                 P.buf.p, P.n_long, P.n_chunks, P.chunk, P.scratch.p, P.scratch_bytes, nullptr));
+        MH_CALL(mh_cspmm_planned_noalloc(L.rp.p, L.ci.p, L.val.p, n, X.p, ld, im, Y2.p, ld, im, alpha, z1, ld, im, b1, nullptr, 0, 0, 0.f, bias, relu, nullptr, F,
+                                         P.n_long ? P.buf.p : nullptr, P.n_long, P.n_chunks, P.chunk, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> y0 = Y0.get(), y1 = Y1.get(), y2 = Y2.get();
+        EXPECT(y1 == y2, "planned and no-allocation entry points differ (variant %d)", variant);
+        // host loop in double on the device's CSR, pre-activation
+        double worst = 0, scale = 0;
+        std::vector<uint8_t> m1 = relu ? M1.get() : std::vector<uint8_t>();
+        for (int32_t r = 0; r < n; r += std::max(1, n / 400)) {
+            for (int32_t f = 0; f < F; ++f) {
+                double are = 0, aim = 0;
+                for (int32_t j = rp[size_t(r)]; j < rp[size_t(r) + 1]; ++j) {
+                    const double vr = val[2 * size_t(j)], vi = val[2 * size_t(j) + 1];
+                    const double xr = hx[(size_t(ci[size_t(j)]) * 2) * F + f], xi = hx[(size_t(ci[size_t(j)]) * 2 + 1) * F + f];
+                    are += vr * xr - vi * xi; aim += vr * xi + vi * xr;
+                }
+                are *= alpha; aim *= alpha;
+                if (z1) { are += b1 * hz[(size_t(r) * 2) * F + f]; aim += b1 * hz[(size_t(r) * 2 + 1) * F + f]; }
+                if (bias) { are += hb[size_t(f)]; aim += hb[size_t(f)]; }
+                const float gr = y1[(size_t(r) * 2) * F + f], gi = y1[(size_t(r) * 2 + 1) * F + f];
+                if (relu) {
+                    const bool on = m1[size_t(r) * F + f] != 0;
+                    if (std::fabs(are) > 1e-4) EXPECT(on == (are >= 0), "mask[%d][%d] = %d, real part %g", r, f, int(on), are);
+                    if (!on) { are = 0; aim = 0; }
+                }
+                worst = std::max(worst, std::max(std::fabs(are - gr), std::fabs(aim - gi)));
+                scale = std::max(scale, std::max(std::fabs(are), std::fabs(aim)));
+            }
+        }
+        EXPECT(worst <= 1e-5 * scale + 1e-6, "SpMM variant %d against the host loop: %g of %g", variant, worst, scale);
+        EXPECT(max_diff(y0, y1) <= 2e-5 * max_abs(y1) + 1e-6, "plain and planned SpMM differ by %g (variant %d)", max_diff(y0, y1), variant);
+    }
+    // launch-width knob: same bits
+    MH_CALL(mh_cspmm_set_grid_cap(24));
+    MH_CALL(mh_cspmm_planned(L.rp.p, L.ci.p, L.val.p, n, X.p, ld, im, Y0.p, ld, im, 2.0f, Z.p, ld, im, -1.0f, nullptr, 0, 0, 0.f, B.p, 1, nullptr, F,
+                             P.buf.p, P.n_long, P.n_chunks, P.chunk, P.scratch.p, P.scratch_bytes, nullptr));
+    MH_CALL(mh_cspmm_set_grid_cap(0));
+    HIP_OK(hipDeviceSynchronize());
+    EXPECT(Y0.get() == Y1.get(), "a reduced launch width changed the result");
+
+    // ---- whole recursions: mh_cheb_terms against single orders, mh_clenshaw against the sum over mh_cheb_terms
+    const int32_t T = 4;
+    Dev<float> ZZ{NF * T}, ref_k{NF};
+    HIP_OK(hipMemcpy(ZZ.p, X.p, NF * 4, hipMemcpyDeviceToDevice));
+    MH_CALL(mh_cheb_terms(L.rp.p, L.ci.p, L.val.p, n, ZZ.p, int64_t(NF), T, F, P.buf.p, P.n_long, P.n_chunks, P.chunk, P.scratch.p, P.scratch_bytes, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<float> zz = ZZ.get();
+    for (int32_t k = 1; k < T; ++k) {
+        const float* prev = ZZ.p + size_t(k - 1) * NF;
+        const float* prev2 = k >= 2 ? ZZ.p + size_t(k - 2) * NF : nullptr;
+        MH_CALL(mh_cspmm_planned(L.rp.p, L.ci.p, L.val.p, n, prev, ld, im, ref_k.p, ld, im, k == 1 ? 1.0f : 2.0f, prev2, ld, im, k == 1 ? 0.f : -1.0f,
+                                 nullptr, 0, 0, 0.f, nullptr, 0, nullptr, F, P.buf.p, P.n_long, P.n_chunks, P.chunk, P.scratch.p, P.scratch_bytes, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> one = ref_k.get();
+        EXPECT(std::equal(one.begin(), one.end(), zz.begin() + ptrdiff_t(size_t(k) * NF)), "mh_cheb_terms order %d differs from the single-order call", k);
+    }
+    // Clenshaw on Y_k = c_k X: sum_k T_k(L) Y_k = sum_k c_k Z_k
+    const float coef[T] = {0.5f, -1.25f, 0.75f, 2.0f};
+    std::vector<float> hy(NF * T);
+    for (int32_t k = 0; k < T; ++k) for (size_t i = 0; i < NF; ++i) hy[size_t(k) * NF + i] = coef[k] * hx[i];
+    Dev<float> YY, work{NF * 2}, out{NF};
+    YY.put(hy);
+    MH_CALL(mh_clenshaw(L.rp.p, L.ci.p, L.val.p, n, YY.p, int64_t(NF), T, work.p, out.p, B.p, 1, M0.p, F, P.buf.p, P.n_long, P.n_chunks, P.chunk,
+                        P.scratch.p, P.scratch_bytes, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    {
+        std::vector<float> got = out.get(); std::vector<uint8_t> m = M0.get();
+        double worst = 0, scale = 0;
+        for (int32_t r = 0; r < n; ++r)
+            for (int32_t f = 0; f < F; ++f) {
+                double re = hb[size_t(f)], imv = hb[size_t(f)];
+                for (int32_t k = 0; k < T; ++k) {
+                    re += double(coef[k]) * zz[size_t(k) * NF + (size_t(r) * 2) * F + f];
+                    imv += double(coef[k]) * zz[size_t(k) * NF + (size_t(r) * 2 + 1) * F + f];
+                }
+                const bool on = m[size_t(r) * F + f] != 0;
+                if (std::fabs(re) > 1e-3) EXPECT(on == (re >= 0), "Clenshaw mask[%d][%d]", r, f);
+                if (!on) { re = 0; imv = 0; }
+                worst = std::max(worst, std::max(std::fabs(re - got[(size_t(r) * 2) * F + f]), std::fabs(imv - got[(size_t(r) * 2 + 1) * F + f])));
+                scale = std::max(scale, std::max(std::fabs(re), std::fabs(imv)));
+            }
+        EXPECT(worst <= 2e-5 * scale + 1e-5, "mh_clenshaw against the sum of mh_cheb_terms orders: %g of %g", worst, scale);
+    }
+
+    // ---- layout and activation helpers
+    std::vector<float> hre(size_t(n) * F), him(size_t(n) * F);
+    for (size_t i = 0; i < hre.size(); ++i) { hre[i] = float(rng.uni() * 2 - 1); him[i] = float(rng.uni() * 2 - 1); }
+    Dev<float> RE, IM, RE2{hre.size()}, IM2{him.size()}, PK{NF};
+    RE.put(hre); IM.put(him);
+    MH_CALL(mh_pack(RE.p, F, IM.p, F, PK.p, ld, im, n, F, nullptr));
+    MH_CALL(mh_unpack(PK.p, ld, im, RE2.p, F, IM2.p, F, n, F, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    {
+        std::vector<float> pk = PK.get();
+        bool ok = true;
+        for (int32_t r = 0; r < n && ok; ++r) for (int32_t f = 0; f < F; ++f)
+            ok = ok && pk[(size_t(r) * 2) * F + f] == hre[size_t(r) * F + f] && pk[(size_t(r) * 2 + 1) * F + f] == him[size_t(r) * F + f];
+        EXPECT(ok, "mh_pack layout");
+        EXPECT(RE2.get() == hre && IM2.get() == him, "mh_unpack(mh_pack(.)) is not the identity");
+    }
+    std::vector<int32_t> pick;
+    for (int32_t r = n - 1; r >= 0; r -= 3) pick.push_back(r);
+    Dev<int32_t> IDX; IDX.put(pick);
+    Dev<float> BUF{pick.size() * 2 * size_t(F)}, BACK{NF};
+    HIP_OK(hipMemset(BACK.p, 0, NF * 4));
+    MH_CALL(mh_gather_rows(PK.p, ld, im, IDX.p, int64_t(pick.size()), BUF.p, F, nullptr));
+    MH_CALL(mh_scatter_rows(BUF.p, IDX.p, int64_t(pick.size()), BACK.p, ld, im, F, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    {
+        std::vector<float> pk = PK.get(), bk = BACK.get(), bf = BUF.get();
+        bool ok = true;
+        for (size_t k = 0; k < pick.size() && ok; ++k)
+            ok = std::equal(bf.begin() + ptrdiff_t(k * 2 * F), bf.begin() + ptrdiff_t((k + 1) * 2 * F), pk.begin() + ptrdiff_t(size_t(pick[k]) * 2 * F)) &&
+                 std::equal(bf.begin() + ptrdiff_t(k * 2 * F), bf.begin() + ptrdiff_t((k + 1) * 2 * F), bk.begin() + ptrdiff_t(size_t(pick[k]) * 2 * F));
+        EXPECT(ok, "mh_gather_rows / mh_scatter_rows");
+    }
+    Dev<uint8_t> MK{size_t(n) * size_t(F)};
+    Dev<float> G, GO{NF};
+    G.put(hz);
+    MH_CALL(mh_bias_relu(PK.p, ld, im, B.p, 1, MK.p, n, F, nullptr));
+    MH_CALL(mh_relu_bwd_to(G.p, ld, im, MK.p, GO.p, ld, im, n, F, nullptr));
+    MH_CALL(mh_relu_bwd(G.p, ld, im, MK.p, n, F, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    {
+        std::vector<float> act = PK.get(), g = G.get(), go = GO.get(); std::vector<uint8_t> mk = MK.get();
+        bool ok = true, okg = true;
+        for (int32_t r = 0; r < n; ++r) for (int32_t f = 0; f < F; ++f) {
+            const float pre = hre[size_t(r) * F + f] + hb[size_t(f)], pim = him[size_t(r) * F + f] + hb[size_t(f)];
+            const bool on = pre >= 0.f;
+            ok = ok && (mk[size_t(r) * F + f] != 0) == on && act[(size_t(r) * 2) * F + f] == (on ? pre : 0.f) * 1.0f && act[(size_t(r) * 2 + 1) * F + f] == (on ? pim : 0.f * pim);
+            for (int p = 0; p < 2; ++p) {
+                const float want = on ? hz[(size_t(r) * 2 + p) * F + f] : 0.f * hz[(size_t(r) * 2 + p) * F + f];
+                okg = okg && g[(size_t(r) * 2 + p) * F + f] == want && go[(size_t(r) * 2 + p) * F + f] == want;
+            }
+        }
+        EXPECT(ok, "mh_bias_relu");
+        EXPECT(okg, "mh_relu_bwd / mh_relu_bwd_to");
+    }
+}
+
+int main() {
+    EXPECT(mh_version() >= 200, "version %d", mh_version());
+    MH_CALL(mh_cspmm_noalloc_init());
+    // argument errors come back as codes with a message, not as crashes
+    int64_t nnz = 0;
+    int rc = mh_lap_build_count(nullptr, nullptr, 0, nullptr, 10, 5, 2.0, 0, nullptr, 0, nullptr, &nnz, nullptr);
+    EXPECT(rc < 0 && std::strlen(mh_last_error()) > 0, "null edge lists accepted (rc %d)", rc);
+    {
+        Dev<float> buf{size_t(1) << 20}, sink{1};
+        HIP_OK(hipMemset(buf.p, 0, buf.n * 4));
+        MH_CALL(mh_stream_read(buf.p, buf.n * 4, sink.p, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+    }
+    run_case("tiny", 7, 30, 4, 0.25, 2.0, false, 0, 1);
+    run_case("unweighted-hubs", 20000, 600000, 64, 0.25, 2.0, false, 0, 2);
+    run_case("weighted-lam3", 5000, 120000, 20, 0.1, 3.0, true, 0, 3);
+    run_case("gcn-odd-width", 3000, 40000, 7, 0.05, 2.0, false, 1, 4);
+    run_case("weighted-wide", 1500, 60000, 260, 0.2, 2.0, true, 0, 5);
+    if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 4; }
+    printf("sweep ok\n");
+    fflush(stdout);
+#ifdef ABI_SWEEP_SKIP_TEARDOWN
+    // host-sanitizer build: the sanitizer runtime's allocator aborts ("dev_runtime_unloaded_") when the HIP runtime frees
+    // its own memory from an exit handler, after every check of this program has passed; leave without exit handlers
+    _exit(0);
+#endif
+    return 0;
+}

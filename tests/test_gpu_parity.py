@@ -596,6 +596,19 @@ def test_c_abi_from_a_plain_cpp_caller():
     assert_close(y[:, 0], want.real); assert_close(y[:, 1], want.imag)
 
 
+def test_c_abi_sweep_from_a_plain_cpp_caller():
+    """tests/abi/abi_sweep.cpp: every entry point (builder whole and by row blocks, halo plan, the three SpMM entry points
+    with all epilogues, hub-row plan, launch-width knob, whole recursions, layout / activation / staging helpers) called
+    from plain C++ on five seeded graphs, the builder against the definition in double precision, the rest against host
+    loops and against each other."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, 'tests', 'abi', 'abi_sweep')
+    assert os.path.isfile(exe), 'tests/abi/abi_sweep is not built (make -C magnet_amd/csrc)'
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith('sweep ok'), (res.stdout[-200:], res.stderr[-3000:])
+
+
 def test_c_abi_exchange_from_a_plain_cpp_caller():
     """The same program with `exchange`: mh_exchange_* from a process without torch — the library loads RCCL by itself,
     creates a one-rank communicator that serves itself, and the halo buffer receives exactly the packed rows."""
