@@ -1571,7 +1571,7 @@ def test_integration_stub_from_the_docs_runs():
 
 
 def test_relabelling_snippet_from_the_docs_runs():
-    """The multi-GPU relabelling recipe of INTEGRATION.md, executed as written with one rank."""
+    """The multi-GPU relabelling recipe from the integration notes (the file read below), executed as written with one rank."""
     import re
     _, lap, _, _, _ = _mods()
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
