@@ -96,6 +96,19 @@ int mh_lap_block_count(const void* fwd_row, const void* fwd_col, const float* fw
                        int weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
                        void* workspace, size_t workspace_bytes, int32_t* row_ptr_block, float* dinv_block,
                        int64_t* nnz_host, void* stream);
+/* mh_lap_block_count with the record count of every node of the WHOLE graph, node_records[n_nodes] (device int32:
+ * out-degree + in-degree of the node over all edges, duplicates counted, a self-loop counted twice — what the row of
+ * that node holds in the whole-graph build; NULL = mh_lap_block_count).  Unweighted builds then carry a column's count
+ * through the sort in spare key bits and mh_lap_block_fill computes d^-1/2 of an entry's column from it instead of
+ * gathering it from dinv_full, as the whole-graph build does from its own column groups (a block's records do not hold a
+ * column's other records, hence the table).  The counts must be exact: they stand for dinv_full of the columns.  Same
+ * results, bit for bit; ignored for weighted builds and for sizes whose keys have no spare bits.  No counterpart in
+ * the single-device reference (src/utils/preprocess.py:177-181). */
+int mh_lap_block_count_tagged(const void* fwd_row, const void* fwd_col, const float* fwd_w, int64_t n_fwd,
+                              const void* bwd_row, const void* bwd_col, const float* bwd_w, int64_t n_bwd, int idx64,
+                              int weighted, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
+                              const int32_t* node_records, void* workspace, size_t workspace_bytes,
+                              int32_t* row_ptr_block, float* dinv_block, int64_t* nnz_host, void* stream);
 int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double q,
                       double max_eigen, int weighted, void* workspace, size_t workspace_bytes, int64_t nnz,
                       const float* dinv_full, int32_t* col_idx, float* val, void* stream);

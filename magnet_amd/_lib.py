@@ -44,6 +44,9 @@ def _load():
     lib.mh_lap_block_count.restype = C.c_int
     lib.mh_lap_block_count.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, C.c_int, C.c_int, i32, i32, i32, f64, vp, sz, vp, vp,
                                        C.POINTER(i64), vp]
+    lib.mh_lap_block_count_tagged.restype = C.c_int
+    lib.mh_lap_block_count_tagged.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, C.c_int, C.c_int, i32, i32, i32, f64, vp, vp, sz, vp,
+                                              vp, C.POINTER(i64), vp]
     lib.mh_lap_block_fill.restype = C.c_int
     lib.mh_lap_block_fill.argtypes = [i64, i64, i32, i32, i32, f64, f64, C.c_int, vp, sz, i64, vp, vp, vp, vp]
     lib.mh_cspmm.restype = C.c_int
@@ -153,7 +156,7 @@ ops = _Ops()
 EXPORTS = [
     'mh_version', 'mh_last_error',
     'mh_lap_workspace_bytes', 'mh_lap_build_count', 'mh_lap_build_fill',
-    'mh_lap_block_workspace_bytes', 'mh_lap_block_count', 'mh_lap_block_fill',
+    'mh_lap_block_workspace_bytes', 'mh_lap_block_count', 'mh_lap_block_count_tagged', 'mh_lap_block_fill',
     'mh_cspmm', 'mh_cspmm_planned', 'mh_cspmm_planned_noalloc', 'mh_cspmm_noalloc_init', 'mh_cspmm_set_grid_cap', 'mh_cspmm_plan_ints', 'mh_cspmm_plan_count', 'mh_cspmm_plan_fill',
     'mh_cheb_terms', 'mh_clenshaw',
     'mh_halo_plan_workspace_bytes', 'mh_halo_plan_count', 'mh_halo_plan_fill',

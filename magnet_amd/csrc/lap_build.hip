@@ -529,10 +529,11 @@ __global__ void __launch_bounds__(kBlock) emit_entries(const uint64_t* __restric
         const bool kept = (words[u] >> lane) & 1ull;
         d_row[u] = d_col[u] = 0.0f;
         if (kept) {
-            const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : kTagCap;
+            // a column that occurs in a record has at least one record: a zero tag is a key that was not tagged
+            const uint32_t tag = tagged ? uint32_t(k >> (2 * cb + 1)) : 0u;
             d_row[u] = dinv[int32_t((k >> (cb + 1)) & node_mask)];
-            d_col[u] = tag < kTagCap ? tag_table[tag]      // the column's record count travelled in the key
-                                     : dinv[int32_t((k >> 1) & node_mask)];
+            d_col[u] = (tag != 0u && tag < kTagCap) ? tag_table[tag]      // the column's record count travelled in the key
+                                                    : dinv[int32_t((k >> 1) & node_mask)];
         }
     }
 #pragma unroll
@@ -619,8 +620,11 @@ struct EdgeList { const void* row; const void* col; const float* w; int64_t n; i
 // The records are made by the sort's first pass (mhsort::RecordSource).  An odd number of passes moves them
 // "first buffer" -> keys1 when the pass that makes them writes into the buffer chosen here, so that the sorted
 // records always end in keys1 / w1.
+// `node_counts` (tagged sorts only): the record count of every node when the records at hand are not all records of the
+// graph (a row block) - the column groups then say nothing about a node's degree and the caller's table is used.
 int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const EdgeList& bwd, int idx64, bool weighted,
-                     bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream) {
+                     bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi, hipStream_t stream,
+                     const int32_t* node_counts = nullptr) {
     if (L.m <= 0) return MH_OK;
     const bool start_in_0 = mhsort::passes_for(2 * L.cb) & 1;
     uint64_t* rec_keys = start_in_0 ? W.keys0 : W.keys1;          // the buffer the first pass does NOT write
@@ -640,9 +644,11 @@ int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const 
         MH_HIP(mhsort::sort(rec_keys, other, nullptr, nullptr, L.m, 1, L.cb, W.sort, L.sort_bytes, stream, nullptr, &src));
         uint64_t* by_col = (mhsort::passes_for(L.cb) & 1) ? other : rec_keys;
         uint64_t* spare = by_col == rec_keys ? other : rec_keys;
-        row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(by_col, L.m, n_nodes, 1, node_mask, W.rec_ptr);
-        MH_LAUNCH_CHECK("column_starts");
-        const mhsort::Tag tag{W.rec_ptr, 1, uint32_t(node_mask), 2 * L.cb + 1, kTagCap};
+        if (!node_counts) {
+            row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(by_col, L.m, n_nodes, 1, node_mask, W.rec_ptr);
+            MH_LAUNCH_CHECK("column_starts");
+        }
+        const mhsort::Tag tag{W.rec_ptr, node_counts, 1, uint32_t(node_mask), 2 * L.cb + 1, kTagCap};
         MH_HIP(mhsort::sort(by_col, spare, nullptr, nullptr, L.m, L.cb + 1, L.cb, W.sort, L.sort_bytes, stream, &tag));
     }
     MH_LAUNCH_CHECK("sort");
@@ -650,11 +656,11 @@ int records_and_sort(const Layout& L, const Work& W, const EdgeList& fwd, const 
 }
 
 // everything of the count phase after the sort; rows [row_lo, row_hi) are the rows the records belong to
-int count_sorted(const Layout& L, const Work& W, bool weighted, bool tagged, int32_t n_nodes, int32_t row_lo, int32_t row_hi,
+int count_sorted(const Layout& L, const Work& W, bool weighted, bool have_row_starts, int32_t n_nodes, int32_t row_lo, int32_t row_hi,
                  int diag, int32_t* row_ptr, float* dinv_block, int64_t* nnz_host, hipStream_t stream) {
-    // A tagged build has the row starts already: they are the column starts found between the sort's column and row
-    // passes (node j has as many records in row j as in column j, so both are the same running sum).
-    if (!tagged) {
+    // A tagged whole-graph build has the row starts already: they are the column starts found between the sort's column
+    // and row passes (node j has as many records in row j as in column j, so both are the same running sum).
+    if (!have_row_starts) {
         row_starts<<<grid_for(int64_t(n_nodes) + 1), kBlock, 0, stream>>>(W.keys1, L.m, n_nodes, L.cb + 1, (1ull << L.cb) - 1ull,
                                                                           W.rec_ptr);
         MH_LAUNCH_CHECK("row_starts");
@@ -793,6 +799,16 @@ extern "C" int mh_lap_block_count(const void* fwd_row, const void* fwd_col, cons
                                   int weighted_, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
                                   void* workspace, size_t workspace_bytes, int32_t* row_ptr_block, float* dinv_block,
                                   int64_t* nnz_host, void* stream_) {
+    return mh_lap_block_count_tagged(fwd_row, fwd_col, fwd_w, n_fwd, bwd_row, bwd_col, bwd_w, n_bwd, idx64, weighted_, n_nodes,
+                                     row_lo, row_hi, max_eigen, nullptr, workspace, workspace_bytes, row_ptr_block, dinv_block,
+                                     nnz_host, stream_);
+}
+
+extern "C" int mh_lap_block_count_tagged(const void* fwd_row, const void* fwd_col, const float* fwd_w, int64_t n_fwd,
+                                         const void* bwd_row, const void* bwd_col, const float* bwd_w, int64_t n_bwd, int idx64,
+                                         int weighted_, int32_t n_nodes, int32_t row_lo, int32_t row_hi, double max_eigen,
+                                         const int32_t* node_records, void* workspace, size_t workspace_bytes,
+                                         int32_t* row_ptr_block, float* dinv_block, int64_t* nnz_host, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MH_REQUIRE(n_fwd >= 0 && n_bwd >= 0 && n_nodes >= 0, "negative size");
     MH_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= n_nodes, "row block [%d, %d) outside [0, %d]", row_lo, row_hi, n_nodes);
@@ -807,7 +823,11 @@ extern "C" int mh_lap_block_count(const void* fwd_row, const void* fwd_col, cons
     if (rc != MH_OK) return rc;
     const int diag = (float(2.0 / max_eigen) * 1.0f - 1.0f) != 0.0f;
     EdgeList f{fwd_row, fwd_col, fwd_w, n_fwd, 0}, b{bwd_row, bwd_col, bwd_w, n_bwd, 0};
-    rc = records_and_sort(L, W, f, b, idx64, weighted, false, n_nodes, row_lo, row_hi, stream);
+    // the columns' record counts travel in the keys when the caller knows them (the block's own records do not: a column's
+    // other records lie in other blocks); same conditions as for the whole graph.  The rows of the block are complete,
+    // so their starts and degrees come from the block's records as ever.
+    const bool tagged = node_records != nullptr && use_tags(L, weighted, true);
+    rc = records_and_sort(L, W, f, b, idx64, weighted, tagged, n_nodes, row_lo, row_hi, stream, node_records);
     if (rc != MH_OK) return rc;
     return count_sorted(L, W, weighted, false, n_nodes, row_lo, row_hi, diag, row_ptr_block, dinv_block, nnz_host, stream);
 }
@@ -825,5 +845,6 @@ extern "C" int mh_lap_block_fill(int64_t n_fwd, int64_t n_bwd, int32_t n_nodes, 
     if (workspace_bytes < L.total)
         return mh::fail(MH_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, L.total);
     Work W = cut(workspace, L, weighted);
-    return fill_sorted(L, W, false, row_lo, row_hi, q, max_eigen, nnz, dinv_full, col_idx, val, stream);
+    // keys that mh_lap_block_count_tagged tagged carry a non-zero count above their live bits; untagged ones carry zero
+    return fill_sorted(L, W, use_tags(L, weighted, true), row_lo, row_hi, q, max_eigen, nnz, dinv_full, col_idx, val, stream);
 }

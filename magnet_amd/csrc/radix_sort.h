@@ -16,9 +16,11 @@ inline int passes_for(int bits) { return (bits + 7) / 8; }
 // Optional rewrite of the keys on their way through the first pass of a sort() call: the keys arrive ordered by the
 // field (key >> field_shift) & field_mask, starts[f] is the index of the first key of field value f (starts[f + 1] -
 // starts[f] keys carry it), and every key gets min(that count, cap) written into its bits from tag_shift upwards (bits
-// the sort does not look at and that are zero on input).
+// the sort does not look at and that are zero on input).  With `counts` set the count of field value f is counts[f]
+// instead (a table from elsewhere: the keys at hand need not be all keys that carry f) and `starts` is not read.
 struct Tag {
     const int32_t* starts;
+    const int32_t* counts;
     int field_shift;
     uint32_t field_mask;
     int tag_shift;

@@ -329,7 +329,7 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
         if (TAG && ok) {
             // the keys arrive grouped by the field, so neighbouring lanes read the same few entries of starts[]
             const uint32_t f = uint32_t(key[i] >> tag.field_shift) & tag.field_mask;
-            const uint32_t cnt = uint32_t(tag.starts[f + 1] - tag.starts[f]);
+            const uint32_t cnt = tag.counts ? uint32_t(tag.counts[f]) : uint32_t(tag.starts[f + 1] - tag.starts[f]);
             key[i] |= uint64_t(cnt < tag.cap ? cnt : tag.cap) << tag.tag_shift;
         }
     }

@@ -256,7 +256,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> lap_build(const Tensor& row, const Te
 // lap_block_fill once the ranks have gathered each other's dinv_block.
 std::tuple<Tensor, Tensor, Tensor, int64_t> lap_block_count(const Tensor& fwd_row, const Tensor& fwd_col, const OptTensor& fwd_w,
                                                             const Tensor& bwd_row, const Tensor& bwd_col, const OptTensor& bwd_w,
-                                                            int64_t n_nodes, int64_t row_lo, int64_t row_hi, double max_eigen) {
+                                                            int64_t n_nodes, int64_t row_lo, int64_t row_hi, double max_eigen,
+                                                            const OptTensor& node_records) {
     const c10::DeviceGuard guard(fwd_row.device());
     const Tensor* idx[4] = {&fwd_row, &fwd_col, &bwd_row, &bwd_col};
     for (const Tensor* t : idx) {
@@ -283,10 +284,17 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> lap_block_count(const Tensor& fwd_ro
     Tensor row_ptr = at::empty({row_hi - row_lo + 1}, fwd_row.options().dtype(at::kInt));
     Tensor dinv = at::empty({row_hi - row_lo}, fwd_row.options().dtype(at::kFloat));
     int64_t nnz = 0;
-    check_rc(mh_lap_block_count(fwd_row.data_ptr(), fwd_col.data_ptr(), fw, n_fwd, bwd_row.data_ptr(), bwd_col.data_ptr(), bw, n_bwd,
-                                fwd_row.scalar_type() == at::kLong, weighted, int32_t(n_nodes), int32_t(row_lo), int32_t(row_hi),
-                                max_eigen, ws.data_ptr(), ws_bytes, row_ptr.data_ptr<int32_t>(), dinv.data_ptr<float>(), &nnz,
-                                stream_of(fwd_row)), "lap_block_count");
+    const int32_t* counts = nullptr;
+    if (node_records.has_value() && node_records->defined()) {
+        need_cuda(*node_records, "node_records");
+        TORCH_CHECK(node_records->scalar_type() == at::kInt && node_records->is_contiguous() && node_records->numel() == n_nodes,
+                    "node_records must be contiguous int32 [n_nodes]");
+        counts = node_records->data_ptr<int32_t>();
+    }
+    check_rc(mh_lap_block_count_tagged(fwd_row.data_ptr(), fwd_col.data_ptr(), fw, n_fwd, bwd_row.data_ptr(), bwd_col.data_ptr(), bw,
+                                       n_bwd, fwd_row.scalar_type() == at::kLong, weighted, int32_t(n_nodes), int32_t(row_lo),
+                                       int32_t(row_hi), max_eigen, counts, ws.data_ptr(), ws_bytes, row_ptr.data_ptr<int32_t>(),
+                                       dinv.data_ptr<float>(), &nnz, stream_of(fwd_row)), "lap_block_count");
     return std::make_tuple(ws, row_ptr, dinv, nnz);
 }
 
@@ -507,7 +515,7 @@ TORCH_LIBRARY(magnet, m) {
     m.def("lap_build(Tensor row, Tensor col, Tensor? weight, int n_nodes, float q, float max_eigen, bool gcn_appr) -> "
           "(Tensor, Tensor, Tensor, Tensor)");
     m.def("lap_block_count(Tensor fwd_row, Tensor fwd_col, Tensor? fwd_w, Tensor bwd_row, Tensor bwd_col, Tensor? bwd_w, "
-          "int n_nodes, int row_lo, int row_hi, float max_eigen) -> (Tensor, Tensor, Tensor, int)");
+          "int n_nodes, int row_lo, int row_hi, float max_eigen, Tensor? node_records) -> (Tensor, Tensor, Tensor, int)");
     m.def("lap_block_fill(Tensor ws, int n_fwd, int n_bwd, int n_nodes, int row_lo, int row_hi, float q, float max_eigen, "
           "bool weighted, int nnz, Tensor dinv_full) -> (Tensor, Tensor)");
     m.def("pack(Tensor real, Tensor imag, Tensor(a!) out) -> ()");

@@ -594,8 +594,8 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
     HIP events) apart from the streaming, counting and selection of the edges around it."""
     from .laplacian import LaplacianBlockBuild
     dev = None
+    deg = None                                       # records per node (out-degree + in-degree over all edges)
     if bounds is None:
-        deg = None
         for chunk in edge_chunks():
             row, col = chunk[0], chunk[1]
             dev = row.device
@@ -604,7 +604,7 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
         if deg is None:
             raise ValueError('edge_chunks() yielded nothing')
         bounds = bounds_from_degrees(deg, world)
-        del deg
+    count_here = deg is None                         # bounds were given: the records are counted in the pass below
     r0, r1 = bounds[rank], bounds[rank + 1]
     parts = [[], [], [], [], [], []]                 # fwd row, col, w ; bwd row, col, w
     weighted = None
@@ -616,6 +616,9 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
         elif weighted != (w is not None):
             raise ValueError('edge_chunks() mixes chunks with and without weights')
         dev = row.device
+        if count_here and row.is_cuda:
+            d = torch.bincount(row.long(), minlength=n) + torch.bincount(col.long(), minlength=n)
+            deg = d if deg is None else deg + d
         f = (row >= r0) & (row < r1)
         b = (col >= r0) & (col < r1)
         parts[0].append(row[f]); parts[1].append(col[f])
@@ -632,8 +635,11 @@ def build_row_block(edge_chunks, n, rank, world, q=0.25, group=None, bounds=None
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    build = LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=max_eigen)
-    del fwd, bwd
+    # every node's record count lets the block build carry the columns' degrees through its sort (unweighted builds)
+    records = None if (weighted or deg is None) else deg.to(torch.int32)
+    del deg
+    build = LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=max_eigen, node_records=records)
+    del fwd, bwd, records
     dinv = torch.zeros(n, dtype=torch.float32, device=dev)
     dinv[r0:r1] = build.dinv_block
     if world > 1:

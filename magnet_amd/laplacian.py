@@ -307,9 +307,13 @@ class LaplacianBlockBuild:
         b.dinv_block                                      # d^-1/2 of the block's rows -> gather over the ranks
         lap = b.finish(dinv_full, q)                      # CSR of the block, GLOBAL column ids
 
-    The blocks of a partition, stacked, are bit for bit the CSR build_magnetic_laplacian returns."""
+    The blocks of a partition, stacked, are bit for bit the CSR build_magnetic_laplacian returns.
+    `node_records` (optional, unweighted builds): int32 [n], out-degree + in-degree of every node over ALL edges of the
+    graph (duplicates counted, a self-loop twice).  With it a column's count travels through the sort in the keys'
+    spare bits and the fill computes d^-1/2 of the columns from it instead of gathering it from dinv_full
+    (mh_lap_block_count_tagged); the counts must be exact."""
 
-    def __init__(self, fwd, bwd, size, r0, r1, max_eigen=2.0):
+    def __init__(self, fwd, bwd, size, r0, r1, max_eigen=2.0, node_records=None):
         def norm(lst):
             row, col = lst[0], lst[1]
             w = lst[2] if len(lst) > 2 else None
@@ -328,8 +332,10 @@ class LaplacianBlockBuild:
         self.n, self.r0, self.r1, self.max_eigen = int(size), int(r0), int(r1), float(max_eigen)
         self.n_fwd, self.n_bwd, self.weighted = fr.numel(), br.numel(), fw is not None
         with torch.cuda.device(fr.device):
+            if node_records is not None:
+                node_records = None if self.weighted else node_records.to(device=fr.device, dtype=torch.int32).contiguous()
             self._ws, self.row_ptr, self.dinv_block, self.nnz = ops.lap_block_count(
-                fr, fc, fw, br, bc, bw, self.n, self.r0, self.r1, self.max_eigen)
+                fr, fc, fw, br, bc, bw, self.n, self.r0, self.r1, self.max_eigen, node_records)
 
     def finish(self, dinv_full, q=0.25):
         with torch.cuda.device(dinv_full.device):

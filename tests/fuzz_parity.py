@@ -308,13 +308,16 @@ def dist_case(rng):
     L = lapmod.build_magnetic_laplacian(row, col, n, q=q, edge_weight=w, max_eigen=lam)
     deg = torch.bincount(row.long(), minlength=n) + torch.bincount(col.long(), minlength=n)
     bounds = D.bounds_from_degrees(deg, world)
+    use_counts = bool(rng.integers(0, 2))
     builds = []
     for r in range(world):
         r0, r1 = bounds[r], bounds[r + 1]
         fm, bm = (row >= r0) & (row < r1), (col >= r0) & (col < r1)
         fwd = (row[fm], col[fm]) + ((w[fm],) if w is not None else ())
         bwd = (row[bm], col[bm]) + ((w[bm],) if w is not None else ())
-        builds.append(lapmod.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam))
+        # unweighted builds: half of the cases hand the ranks every node's record count (tagged keys where the size allows)
+        builds.append(lapmod.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam,
+                                                 node_records=deg.int() if (w is None and use_counts) else None))
     dinv = torch.cat([b.dinv_block for b in builds])
     assert torch.equal(dinv, L.dinv), 'dinv'
     blocks = [b.finish(dinv, q) for b in builds]

@@ -770,14 +770,21 @@ def test_relabelled_graph_gives_the_same_orders_with_a_smaller_halo():
     assert float((got - ref[-1]).abs().max()) <= 1e-5 * float(ref[-1].abs().max())
 
 
-@pytest.mark.parametrize('case', ['unweighted', 'weighted', 'lambda3'])
+@pytest.mark.parametrize('case', ['unweighted', 'weighted', 'lambda3', 'tagged', 'tagged_hub'])
 def test_row_blocks_built_per_rank_stack_to_the_full_laplacian(case):
     """Every rank builds only its own row block from the edges incident to it (mh_lap_block_*); the blocks of
-    a partition, stacked, equal the single-GPU CSR bit for bit (structure and values)."""
+    a partition, stacked, equal the single-GPU CSR bit for bit (structure and values).  'tagged': the ranks are given
+    every node's record count, so the columns' degrees travel in the sort keys (mh_lap_block_count_tagged; 30 000
+    nodes = 15 bits: the column digits fill whole passes); 'tagged_hub': one node with more records than the keys'
+    spare bits can hold, whose entries fall back to the gathered d^-1/2."""
     _, lap, H, M, O = _mods()
     from magnet_amd import dist as D
     n, e, world = 30000, 500000, 4
     src, dst = lap.powerlaw_edges(n, e, 33, device=DEV)
+    if case == 'tagged_hub':
+        extra = torch.randint(0, n, (40000,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)).int()
+        src, dst = torch.cat([src, torch.full_like(extra, 3), extra[:5000]]), torch.cat([dst, extra, torch.full_like(extra[:5000], 3)])
+        e = src.numel()
     w = None
     if case == 'weighted':
         w = (torch.rand(e, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 3 + 0.25)
@@ -792,7 +799,10 @@ def test_row_blocks_built_per_rank_stack_to_the_full_laplacian(case):
         fm, bm = (src >= r0) & (src < r1), (dst >= r0) & (dst < r1)
         fwd = (src[fm], dst[fm]) + ((w[fm],) if w is not None else ())
         bwd = (src[bm], dst[bm]) + ((w[bm],) if w is not None else ())
-        builds.append(lap.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam))
+        builds.append(lap.LaplacianBlockBuild(fwd, bwd, n, r0, r1, max_eigen=lam,
+                                              node_records=deg.int() if case.startswith('tagged') else None))
+    if case == 'tagged_hub':
+        assert int(deg.max()) > 32767
     dinv = torch.cat([b.dinv_block for b in builds])
     assert torch.equal(dinv, L.dinv)
     blocks = [b.finish(dinv, 0.2) for b in builds]
