@@ -290,7 +290,7 @@ def dist_case(rng):
     from magnet_amd import dist as D
     from magnet_amd import laplacian as lapmod
     dev = torch.device('cuda', 0)
-    n = int(rng.choice([1, 2, 5, 40, 300, 3000, 30000]))
+    n = int(rng.choice([1, 2, 5, 40, 200, 300, 3000, 9000, 30000]))      # 40, 200, 9000, 30000: sizes whose keys can carry tags
     e = int(rng.integers(0, 25 * n + 1))
     world = int(rng.integers(1, 6))
     row = torch.from_numpy(rng.integers(0, n, e)).to(dev); col = torch.from_numpy(rng.integers(0, n, e)).to(dev)
