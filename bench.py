@@ -198,14 +198,18 @@ def cpu_baseline(args):
     }
 
 
-def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'):
+def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols', budget_s=None):
     """Secondary metric: one training epoch (train forward + backward + Adam, then an evaluation
     forward: reference src/sparse_Magnet.py:143-176) of a 2-layer ChebNet, 128 -> 128 -> 128 filters,
     K = 2, q = 0.25, complex ReLU, 5 classes, on BASELINE.json config 4 (power-law digraph, 2M nodes /
     40M edges, 128 input features).  With several ranks: layout 'rows' = magnet_amd.dist.RowShardedChebNet over row
     blocks that every rank builds for itself (build_row_block: no rank holds the whole Laplacian), layout 'cols' =
-    ShardedChebNet (every rank holds the whole CSR, layers alternate between row blocks and column slices)."""
+    ShardedChebNet (every rank holds the whole CSR, layers alternate between row blocks and column slices).
+    `budget_s`: seconds this measurement may take; the plain epoch is always timed, the variants after it (first layer's
+    orders kept, shared forward) only while the time already spent plus their predicted cost stays inside the budget —
+    decided from numbers reduced over the ranks, so every rank decides alike."""
     import torch.distributed as dist
+    t_begin = time.time()
     from magnet_amd.laplacian import build_magnetic_laplacian, powerlaw_edges, MagneticLaplacian
     from magnet_amd.layer.sparse_magnet import ChebNet, ChebConv
     from magnet_amd.utils.hermitian import ChebBasis
@@ -273,21 +277,39 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
             dt = t.item()
         return dt / iters * 1e3
 
+    skipped = []
+
+    def affordable(n_timed, what):
+        """Whether n_timed more calls of timed() (7 epochs each, at most as slow as the plain epoch) fit the budget;
+        the same answer on every rank."""
+        if budget_s is None:
+            return True
+        v = torch.tensor([time.time() - t_begin, -float(budget_s)], device=dev, dtype=torch.float64)
+        if multi:
+            from magnet_amd.dist import all_reduce
+            all_reduce(v, op=dist.ReduceOp.MAX)          # longest time spent, smallest budget
+        ok = v[0].item() + n_timed * 7 * ms / 1e3 <= -v[1].item()
+        if not ok:
+            skipped.append(what)
+        return ok
+
     ChebConv.cache_input_propagation = False       # every forward recomputes T_k(L) X, as the reference does
     ms = timed()
+    ms_cached = shared_ms = shared_cached_ms = None
     ChebConv.cache_input_propagation = True        # first layer's weight-independent T_k(L) X kept across forwards
     if multi:
         sh.cache_input_propagation = True
-    ms_cached = timed()
-    shared_ms = shared_cached_ms = None
+    if affordable(1, 'cached_input_propagation'):
+        ms_cached = timed()
     if multi:
-        sh.shared_forward = True                   # the same over the ranks (ShardedChebNet.shared_forward)
-        shared_cached_ms = timed()
-        sh.cache_input_propagation = False
-        sh._kept_pass = sh._input_cache = None
-        shared_ms = timed()
-        sh.shared_forward, sh._kept_pass = False, None
-    else:
+        if affordable(2, 'shared_forward'):
+            sh.shared_forward = True               # the same over the ranks (ShardedChebNet.shared_forward)
+            shared_cached_ms = timed()
+            sh.cache_input_propagation = False
+            sh._kept_pass = sh._input_cache = None
+            shared_ms = timed()
+            sh.shared_forward, sh._kept_pass = False, None
+    elif affordable(2, 'shared_forward'):
         # the evaluation's pass through the convolutions kept for the next epoch's training step (same weights, same
         # tensor: magnet_amd.train.SharedForwardEpochs): one forward per epoch instead of two, identical results
         shared = SharedForwardEpochs(net, opt)
@@ -308,6 +330,8 @@ def epoch_time(rank, world, dev, multi, n=2_000_000, e=40_000_000, layout='cols'
            'n_gpus': world, 'nnz': nnz, 'layout': layout if multi else 'single',
            'config': 'config 4: power-law digraph N=%d E=%d, ChebNet 128->128->128, K=2, q=0.25, 2 layers, '
                      'train fwd+bwd+Adam + eval fwd' % (n, e) + (kind[layout] if multi else '')}
+    if skipped:
+        out['skipped_for_time'] = skipped
     out.update(extra)
     return out
 
@@ -693,6 +717,8 @@ def main():
             os._exit(0)
         if out is not None:
             out['epoch'] = {'error': 'secondary measurements did not finish within 360 s'}
+            if epoch_results:                           # what had finished by then stays on record
+                out['epoch']['layouts'] = dict(epoch_results)
         sys.stderr.write('bench.py: secondary measurements did not finish within 360 s; headline printed, exiting with status 3\n')
         sys.stderr.flush()
         emit()
@@ -700,6 +726,8 @@ def main():
 
     import threading
     rconv = None
+    epoch_results = {}
+    t_secondary = time.time()
     watchdog = threading.Timer(360.0, give_up)
     watchdog.daemon = True
     watchdog.start()
@@ -736,11 +764,14 @@ def main():
         layer = conv = xp = block = lap = lap_blk = None
         torch.cuda.empty_cache()
         layouts = (['rows', 'cols'] if args.epoch_layout == 'both' else [args.epoch_layout]) if multi else ['single']
-        results = {}
-        for lay in layouts:
+        results = epoch_results
+        for i, lay in enumerate(layouts):
             note(rank, 'epoch measurement (config 4, layout %s)' % lay)
+            # an equal share of what is left of the 360 s (minus a reserve): a slow transport (the gloo rehearsal stages
+            # every transfer through the host) then drops the optional variants instead of tripping the watchdog
+            budget = max(300.0 - (time.time() - t_secondary), 0.0) / (len(layouts) - i)
             try:
-                results[lay] = epoch_time(rank, world, dev, multi, args.epoch_nodes, args.epoch_edges, lay)
+                results[lay] = epoch_time(rank, world, dev, multi, args.epoch_nodes, args.epoch_edges, lay, budget_s=budget)
             except Exception as ex:                         # the headline metric must still be reported
                 results[lay] = {'error': repr(ex)[:300]}
             torch.cuda.empty_cache()
