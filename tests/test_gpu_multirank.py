@@ -345,8 +345,11 @@ def test_bench_two_rank_rehearsal_on_one_gpu(strategy):
     assert ep['ms'] > 0 and ep['n_gpus'] == 2 and set(ep['layouts']) == {'rows', 'cols'}
     for lay in ('rows', 'cols'):
         e = ep['layouts'][lay]
-        assert e['ms'] > 0 and e['ms_with_cached_input_propagation'] > 0 and e['layout'] == lay, e
-        assert e['ms_with_shared_forward'] > 0 and e['ms_with_shared_forward_and_cached_input_propagation'] > 0, e
+        assert e['ms'] > 0 and e['layout'] == lay, e
+        # the variants after the plain epoch are timed while the leg's time budget lasts (a slow box may drop them, and says so)
+        for key, what in (('ms_with_cached_input_propagation', 'cached_input_propagation'), ('ms_with_shared_forward', 'shared_forward'),
+                          ('ms_with_shared_forward_and_cached_input_propagation', 'shared_forward')):
+            assert (e[key] is not None and e[key] > 0) or what in e.get('skipped_for_time', []), (key, e)
     assert 'RowShardedChebNet' in ep['layouts']['rows']['config'] and ep['layouts']['rows']['block_build_ms_rank0'] > 0
     assert ep['layouts']['rows']['nnz'] == ep['layouts']['cols']['nnz']
     assert ep['ms'] == min(ep['layouts'][l]['ms'] for l in ep['layouts'])
