@@ -360,3 +360,57 @@ def test_relabelling_for_the_row_partition():
     # a partitioner of one's own plugs in the same way: the true communities give the smallest halo
     t_new, _, t_bounds = P.order_from_parts(comm, world)
     assert halo_rows(t_new[src], t_new[dst], t_bounds) <= after
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.5])
+def test_shared_forward_epochs_on_a_toy_model(dropout):
+    """train.SharedForwardEpochs against train.node_epoch on a small CPU model with the trunk / head split of ChebNet:
+    identical losses, accuracies and parameters, one trunk pass per epoch (plus one) instead of two, and a kept pass
+    that is dropped when a parameter changes behind its back."""
+    from magnet_amd.train import node_epoch, SharedForwardEpochs, NodeTargets
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin, self.out, self.dropout, self.trunk_calls = torch.nn.Linear(6, 5), torch.nn.Linear(10, 3), dropout, 0
+
+        def trunk(self, real, imag):
+            self.trunk_calls += 1
+            return torch.stack([torch.tanh(self.lin(real)), torch.tanh(self.lin(imag))], dim=1)
+
+        def head(self, p):
+            x = p.reshape(p.size(0), -1)
+            if self.dropout > 0:
+                x = torch.nn.functional.dropout(x, self.dropout, training=self.training)
+            return torch.log_softmax(self.out(x), dim=1).t().unsqueeze(0)          # [1, classes, N]
+
+        def forward(self, real, imag):
+            return self.head(self.trunk(real, imag))
+
+    g = torch.Generator().manual_seed(0)
+    n = 40
+    X, Y = torch.randn(n, 6, generator=g), torch.randn(n, 6, generator=g)
+    label = torch.randint(0, 3, (1, n), generator=g)
+    train = torch.rand(n, generator=g) < 0.6
+    tr, va = NodeTargets(label, train), NodeTargets(label, ~train)
+
+    def run(shared, epochs=6, poke_at=3):
+        torch.manual_seed(1)
+        net = Toy()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=5e-4)
+        ep = SharedForwardEpochs(net, opt)
+        torch.manual_seed(2)
+        stats = []
+        for i in range(epochs):
+            if i == poke_at:
+                with torch.no_grad():
+                    net.lin.weight.mul_(1.05)                     # what load_state_dict does: same tensor, new version
+            out = ep.node_epoch(X, Y, label, tr, va) if shared else node_epoch(net, opt, X, Y, label, tr, va)
+            stats.append([float(t) for t in out])
+        return stats, [p.detach().clone() for p in net.parameters()], net.trunk_calls
+
+    s0, p0, calls0 = run(False)
+    s1, p1, calls1 = run(True)
+    assert s0 == s1
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    assert calls0 == 12 and calls1 == 6 + 1 + 1                  # one per epoch, the first epoch's own, one after the poke
