@@ -21,7 +21,7 @@ from .layer.sparse_magnet import ChebNet_Edge
 from .utils.edge_data import in_out_degree, generate_dataset_3class, link_prediction_evaluation, acc, split_cache_prefix
 from .utils.preprocess import to_edge_dataset_sparse
 from .utils.save_settings import write_log
-from .train import link_epoch, GraphedEpoch, SharedForwardEpochs
+from .train import link_epoch, GraphedEpoch, SharedForwardEpochs, GraphedSharedEpochs
 
 
 def parse_args(argv=None):
@@ -121,7 +121,11 @@ def main(args):
         if args.hip_graph:
             # the capture's warm-up epochs are real optimizer steps: rewind parameters and Adam state in place
             start = [p.detach().clone() for p in model.parameters()]
-            body = GraphedEpoch(body)
+            if args.separate_forwards:
+                body = GraphedEpoch(body)
+            else:                                     # the shared-forward epoch as two HIP graphs
+                body = GraphedSharedEpochs.for_links(model, opt, X_real, X_img, idx['train'], y['train'], idx['validate'],
+                                                     y['validate'])
             with torch.no_grad():
                 for p, p0 in zip(model.parameters(), start):
                     p.copy_(p0)

@@ -22,7 +22,7 @@ import torch.optim as optim
 
 from . import data as D
 from .layer.sparse_magnet import ChebNet
-from .train import node_epoch, GraphedEpoch, NodeTargets, SharedForwardEpochs
+from .train import node_epoch, GraphedEpoch, NodeTargets, SharedForwardEpochs, GraphedSharedEpochs
 from .utils.preprocess import geometric_dataset_sparse
 from .utils.save_settings import write_log
 
@@ -200,7 +200,10 @@ def main(args):
         if args.hip_graph:
             # the capture's warm-up epochs are real optimizer steps: rewind parameters and Adam state in place
             start = [p.detach().clone() for p in model.parameters()]
-            body = GraphedEpoch(body)
+            if args.separate_forwards:
+                body = GraphedEpoch(body)
+            else:                                     # the shared-forward epoch as two HIP graphs
+                body = GraphedSharedEpochs.for_nodes(model, opt, X_real, X_img, label, train_targets, val_targets, criterion)
             with torch.no_grad():
                 for p, p0 in zip(model.parameters(), start):
                     p.copy_(p0)

@@ -4,6 +4,7 @@
     node_epoch  — reference src/sparse_Magnet.py:143-176
     link_epoch  — reference src/Edge_sparseMagnet.py:168-199
     SharedForwardEpochs — the same epochs, the evaluation forward shared with the next training forward
+    GraphedSharedEpochs — those replayed as two HIP graphs
 Checkpoint writes (src/sparse_Magnet.py:188-197, src/Edge_sparseMagnet.py:210-215) are the caller's
 business and are not part of the timed epoch.
 """
@@ -157,6 +158,94 @@ class SharedForwardEpochs:
             val_loss = F.nll_loss(out, y_val)
             val_acc = (out.max(dim=1)[1] == y_val).float().mean()
         return train_loss.detach(), train_acc, val_loss, val_acc
+
+
+class GraphedSharedEpochs:
+    """SharedForwardEpochs replayed as HIP graphs: the small reference configurations are bound by kernel launches, and
+    with the shared forward an epoch has a third fewer of them.  Two graphs in one memory pool:
+        A  the evaluation half: trunk pass under the current weights (recorded by autograd), evaluation head, statistics
+        B  the training half:   training head on A's trunk output, loss, backward through A's pass, optimizer step
+    An epoch is B then A (A once more in front of the first epoch), which is the reference's order of operations
+    (src/sparse_Magnet.py:153-176): training step, then the evaluation under the stepped weights.  A's activations live
+    at fixed addresses of the shared pool, so B — captured after A, consuming those tensors — finds on every replay what
+    the latest replay of A wrote there.
+
+    trunk()            -> the convolutions' output p (model.trunk on the fixed inputs)
+    train_stats(p)     -> (loss, accuracy) of the training head on p (called with the model in training mode)
+    eval_stats(p)      -> (loss, accuracy) of the evaluation head on p (evaluation mode, no autograd)
+    The optimizer must be capturable.  The warm-up epochs (at least one: the optimizer's state must exist before the
+    capture, outside the graphs' pool) are real optimizer steps: a caller that wants to start from the initial weights
+    restores parameters and optimizer state in place afterwards (the first call refreshes A).  After a call the
+    parameters' .grad tensors are not meaningful (they live in the pool, where A's replay writes its temporaries);
+    the returned statistics are copied out of the pool inside the graphs."""
+
+    def __init__(self, model, opt, trunk, train_stats, eval_stats, warmup=3):
+        if warmup < 1:
+            raise ValueError('at least one warm-up epoch is needed: the optimizer state must be allocated before the capture')
+        def train_half(p):
+            model.train()
+            loss, acc = train_stats(p)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss.detach(), acc
+
+        def eval_half():
+            model.eval()
+            p = trunk()                                   # recorded: the training half backpropagates through it
+            with torch.no_grad():
+                stats = eval_stats(p.detach())
+            return p, stats
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            p, _ = eval_half()
+            for _ in range(warmup):                       # builds SpMM plans, autotunes GEMMs, primes the allocator
+                train_half(p)
+                p, _ = eval_half()
+            del p
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        # the statistics leave the graphs through buffers outside their pool: what B allocates may lie where A's
+        # temporaries lay (the pool hands freed memory on), and A is replayed after B
+        self.stats = torch.zeros(4, device=next(model.parameters()).device)
+        self.eval_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.eval_graph):
+            p, val = eval_half()
+            self.stats[2].copy_(val[0]); self.stats[3].copy_(val[1])
+        self.train_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.train_graph, pool=self.eval_graph.pool()):
+            tr = train_half(p)
+            self.stats[0].copy_(tr[0]); self.stats[1].copy_(tr[1])
+        del val, tr
+        self._p = p                                       # the pool's memory stays what the graphs address
+        self._primed = False
+
+    def __call__(self):
+        if not self._primed:                              # A under the weights as they are now
+            self.eval_graph.replay()
+            self._primed = True
+        self.train_graph.replay()
+        self.eval_graph.replay()
+        return self.stats[0], self.stats[1], self.stats[2], self.stats[3]
+
+    @classmethod
+    def for_nodes(cls, model, opt, X_real, X_img, label, train_index, val_index, criterion=None, warmup=3):
+        """The epoch of node_epoch (same arguments; index tensors or NodeTargets, not boolean masks)."""
+        criterion = criterion or torch.nn.NLLLoss()
+        return cls(model, opt, lambda: model.trunk(X_real, X_img),
+                   lambda p: _loss_acc(model.head(p), label, train_index, criterion),
+                   lambda p: _loss_acc(model.head(p), label, val_index, criterion), warmup)
+
+    @classmethod
+    def for_links(cls, model, opt, X_real, X_img, train_index, y_train, val_index, y_val, warmup=3):
+        """The epoch of link_epoch (same arguments)."""
+        def stats(p, index, y):
+            out = model.head(p, index)
+            return F.nll_loss(out, y), (out.max(dim=1)[1] == y).float().mean()
+        return cls(model, opt, lambda: model.trunk(X_real, X_img), lambda p: stats(p, train_index, y_train),
+                   lambda p: stats(p, val_index, y_val), warmup)
 
 
 class GraphedEpoch:

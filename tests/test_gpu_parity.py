@@ -1080,6 +1080,45 @@ def test_hip_graph_epoch_replay_matches_eager():
         assert_close(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rel=1e-4)
 
 
+def test_shared_forward_epochs_as_hip_graphs_match_eager():
+    """GraphedSharedEpochs (evaluation half and training half as two HIP graphs in one pool) gives the eager epochs'
+    losses, accuracies and parameters, for the node and the link network."""
+    _, lap, H, M, O = _mods()
+    from magnet_amd.train import node_epoch, link_epoch, GraphedSharedEpochs
+    from magnet_amd.data import dsbm_cyclic
+    g = dsbm_cyclic(n_per_cluster=100, clusters=5, seed=2)
+    n = g.x.size(0)
+    L = H.hermitian_decomp_sparse_device(g.edge_index[0], g.edge_index[1], n, 0.1)
+    X = g.x.to(DEV); y = g.y[None].to(DEV)
+    tr = g.train_mask[:, 0].nonzero().squeeze(1).to(DEV); va = g.val_mask[:, 0].nonzero().squeeze(1).to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    pt = torch.randint(0, n, (300, 2), generator=gen).to(DEV); yt = torch.randint(0, 2, (300,), generator=gen).to(DEV)
+    pv = torch.randint(0, n, (90, 2), generator=gen).to(DEV); yv = torch.randint(0, 2, (90,), generator=gen).to(DEV)
+
+    def make(cls, **kw):
+        torch.manual_seed(5)
+        net = cls(1, H.cheb_poly_sparse(L, 2), None, num_filter=16, K=2, activation=True, layer=2, **kw).to(DEV)
+        return net, torch.optim.Adam(net.parameters(), lr=5e-3, weight_decay=5e-4, capturable=True)
+
+    for kind in ('node', 'link'):
+        cls, kw = (M.ChebNet, dict(label_dim=5)) if kind == 'node' else (M.ChebNet_Edge, dict(label_dim=2))
+        net_e, opt_e = make(cls, **kw)
+        if kind == 'node':
+            eager = [[t.item() for t in node_epoch(net_e, opt_e, X, X, y, tr, va)] for _ in range(8)]
+        else:
+            eager = [[t.item() for t in link_epoch(net_e, opt_e, X, X, pt, yt, pv, yv)] for _ in range(8)]
+        net_g, opt_g = make(cls, **kw)
+        if kind == 'node':
+            ge = GraphedSharedEpochs.for_nodes(net_g, opt_g, X, X, y, tr, va, warmup=3)   # 3 eager warm-up epochs first
+        else:
+            ge = GraphedSharedEpochs.for_links(net_g, opt_g, X, X, pt, yt, pv, yv, warmup=3)
+        replay = [[t.item() for t in ge()] for _ in range(5)]
+        for a, b in zip(eager[3:], replay):
+            assert_close(np.array(b), np.array(a), rel=1e-4, what='%s: graph replay vs eager' % kind)
+        for pe, pg in zip(net_e.parameters(), net_g.parameters()):
+            assert_close(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rel=1e-4, what=kind)
+
+
 @pytest.mark.parametrize('dropout', [0.0, 0.5])
 def test_shared_forward_epochs_match_plain_epochs(dropout):
     """SharedForwardEpochs (the evaluation's pass through the convolutions kept for the next training step) gives the

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from magnet_amd import data as D                                               # noqa: E402
 from magnet_amd.layer.sparse_magnet import ChebNet                              # noqa: E402
 from magnet_amd.utils.hermitian import hermitian_decomp_sparse_device, cheb_poly_sparse   # noqa: E402
-from magnet_amd.train import node_epoch, GraphedEpoch, SharedForwardEpochs      # noqa: E402
+from magnet_amd.train import node_epoch, GraphedEpoch, SharedForwardEpochs, GraphedSharedEpochs      # noqa: E402
 from magnet_amd.sparse_Magnet import sparse_mx_to_torch_sparse_tensor          # noqa: E402
 
 dev = 'cuda'
@@ -62,6 +62,7 @@ def run(name, g, q, K, Fh, layer, iters=200):
     sh.reset()
     graphed = GraphedEpoch(lambda: node_epoch(net, opt, X, X, y, tr, va))
     gms = timeit(graphed, iters)
+    gsh = timeit(GraphedSharedEpochs.for_nodes(net, opt, X, X, y, tr, va), iters)
     # reference formulation on the same GPU
     Ts = list(cheb_poly_sparse(L, K))                     # the sparse T_k the reference precomputes (host SpGEMM)
     Lr = [sparse_mx_to_torch_sparse_tensor(t.real).to(dev) for t in Ts]
@@ -78,7 +79,8 @@ def run(name, g, q, K, Fh, layer, iters=200):
     ref = timeit(ref_epoch, max(iters // 4, 10))
     print(json.dumps(dict(config=name, nodes=n, edges=int(g.edge_index.size(1)), nnz=L.nnz, K=K, filters=Fh,
                           epoch_ms_eager=round(eager, 3), epoch_ms_eager_shared_forward=round(shared, 3),
-                          epoch_ms_hipgraph=round(gms, 3), epoch_ms_reference_formulation_same_gpu=round(ref, 3),
+                          epoch_ms_hipgraph=round(gms, 3), epoch_ms_hipgraph_shared_forward=round(gsh, 3),
+                          epoch_ms_reference_formulation_same_gpu=round(ref, 3),
                           nnz_T=[int(t._nnz()) for t in Lr])), flush=True)
 
 
@@ -105,6 +107,7 @@ def run_link(name, case, iters=200):
     shared = timeit(lambda: sh.link_epoch(X, X, tp, tl, vp, vl), iters)
     sh.reset()
     gms = timeit(GraphedEpoch(lambda: link_epoch(net, opt, X, X, tp, tl, vp, vl)), iters)
+    gsh = timeit(GraphedSharedEpochs.for_links(net, opt, X, X, tp, tl, vp, vl), iters)
     Ts = list(cheb_poly_sparse(L, K))
     Lr = [sparse_mx_to_torch_sparse_tensor(m.real).to(dev) for m in Ts]
     Li = [sparse_mx_to_torch_sparse_tensor(m.imag).to(dev) for m in Ts]
@@ -133,7 +136,7 @@ def run_link(name, case, iters=200):
     ref = timeit(ref_epoch, max(iters // 4, 10))
     print(json.dumps(dict(config=name, nodes=size, edges=int(edges.size(1)), nnz=L.nnz, K=K, filters=16, train_pairs=int(tp.size(0)),
                           epoch_ms_eager=round(eager, 3), epoch_ms_eager_shared_forward=round(shared, 3),
-                          epoch_ms_hipgraph=round(gms, 3),
+                          epoch_ms_hipgraph=round(gms, 3), epoch_ms_hipgraph_shared_forward=round(gsh, 3),
                           epoch_ms_reference_formulation_same_gpu=round(ref, 3), nnz_T=[int(m._nnz()) for m in Lr])), flush=True)
 
 
