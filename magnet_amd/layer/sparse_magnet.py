@@ -135,19 +135,33 @@ def _alloc_out(n, f, next_terms, device):
     return torch.empty((n, 2, f), dtype=torch.float32, device=device)
 
 
+def _slabs(r, min_rows, most):
+    """Largest power of two <= most that divides r into slabs of at least min_rows rows."""
+    slabs = 1
+    while slabs < most and r % (slabs * 2) == 0 and r // (slabs * 2) >= min_rows:
+        slabs *= 2
+    return slabs
+
+
 def _gram(a, b):
     """a^T b for two tall matrices [R, m], [R, n] (R = 2N rows, m, n = channel counts): the weight
     gradient.  A single GEMM has only m*n/tile^2 output tiles to spread over 256 CUs, so the rows are
-    cut into slabs that are multiplied as one batched GEMM and summed (split-K)."""
+    cut into slabs that are multiplied as one batched GEMM and summed (split-K).  Graph-scale row counts take slabs
+    of >= 4096 rows; a few thousand rows (the reference's own datasets, where an epoch is a string of
+    microsecond kernels and a one-workgroup GEMM over all rows is the longest of them) slabs of >= 256."""
     r = a.size(0)
-    if r >= (1 << 16) and a.size(1) * b.size(1) <= (1 << 18):
-        slabs = 1
-        while slabs < 128 and r % (slabs * 2) == 0 and r // (slabs * 2) >= 4096:
-            slabs *= 2
+    if a.size(1) * b.size(1) <= (1 << 18):
+        slabs = _slabs(r, 4096, 128) if r >= (1 << 16) else _slabs(r, 256, 32) if r >= 2048 else 1
         if slabs > 1:
             return torch.bmm(a.unflatten(0, (slabs, r // slabs)).transpose(1, 2),
                              b.unflatten(0, (slabs, r // slabs))).sum(0)
     return torch.mm(a.t(), b)
+
+
+def _col_sums(g):
+    """Sum of a packed gradient [N, 2, F] over nodes and parts -> [F]: the bias gradient (the same real bias sits on
+    both parts, src/layer/sparse_magnet.py:72)."""
+    return g.sum(dim=(0, 1))
 
 
 def _bias_relu_(p, bias, relu):
@@ -319,7 +333,7 @@ class _ChebConvFn(torch.autograd.Function):
             else:
                 g0.copy_(g)
             if need_b:
-                db = g0.sum(dim=(0, 1)).view(1, cout)     # the same real bias sits on both parts
+                db = _col_sums(g0).view(1, cout)          # the same real bias sits on both parts
             if need_w or need_x:
                 _fill_orders(lap, ds)
             if need_w:                                     # X^T [T_0 G ... T_K G] -> [C_in, K+1, C_out]
@@ -329,7 +343,7 @@ class _ChebConvFn(torch.autograd.Function):
         else:
             g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
             if need_b:
-                db = g.sum(dim=(0, 1)).view(1, cout)
+                db = _col_sums(g).view(1, cout)
             g2 = _rows2(g)
             if need_w:
                 block = ctx.block if ctx.block is not None else _cheb_terms(lap, ctx.x0, k1)   # recomputed orders
@@ -376,7 +390,7 @@ class _ClenshawFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
-        db = g.sum(dim=(0, 1)) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        db = _col_sums(g) if ctx.has_bias and ctx.needs_input_grad[1] else None
         dy = _cheb_terms(ctx.lap, g, ctx.k1) if ctx.needs_input_grad[0] else None
         return dy, db, None, None
 
@@ -411,7 +425,7 @@ class _ListConvFn(torch.autograd.Function):
         g = _relu_bwd(g, ctx.mask) if ctx.relu else g.contiguous()
         dx = dw = db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g.sum(dim=(0, 1)).view(1, cout)
+            db = _col_sums(g).view(1, cout)
         g2 = _rows2(g)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
