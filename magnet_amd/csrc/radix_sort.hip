@@ -295,7 +295,7 @@ struct ScatterShared {
 
 // One tile of a pass.  FULL: no key of the tile is out of range (every tile but the last).  NB: digit bits that are
 // matched (8, or 7 for the 7-bit digits of 42-bit keys).  HI: see digit_of2.
-template <bool PAIRS, bool TAG, int NB, bool HI, bool FULL, int GEN>
+template <bool PAIRS, int TAG, int NB, bool HI, bool FULL, int GEN>
 __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint64_t* __restrict__ kin,
                                     uint64_t* __restrict__ kout, const float* __restrict__ vin, float* __restrict__ vout,
                                     int64_t n, int shift, uint32_t mask, uint32_t my_goff, const Tag& tag,
@@ -329,7 +329,9 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
         if (TAG && ok) {
             // the keys arrive grouped by the field, so neighbouring lanes read the same few entries of starts[]
             const uint32_t f = uint32_t(key[i] >> tag.field_shift) & tag.field_mask;
-            const uint32_t cnt = tag.counts ? uint32_t(tag.counts[f]) : uint32_t(tag.starts[f + 1] - tag.starts[f]);
+            // TAG 1: the size of the field value's group among these keys; TAG 2: the caller's table (compile-time
+            // variants: a run-time choice here cost the whole-graph build a tenth of its time)
+            const uint32_t cnt = TAG == 2 ? uint32_t(tag.counts[f]) : uint32_t(tag.starts[f + 1] - tag.starts[f]);
             key[i] |= uint64_t(cnt < tag.cap ? cnt : tag.cap) << tag.tag_shift;
         }
     }
@@ -415,7 +417,7 @@ __device__ inline void scatter_tile(ScatterShared& sh, float* svals, const uint6
     }
 }
 
-template <bool PAIRS, bool TAG, int NB, bool HI, int GEN>
+template <bool PAIRS, int TAG, int NB, bool HI, int GEN>
 __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                     const float* __restrict__ vin, float* __restrict__ vout, int64_t n,
                                                     int shift, uint32_t mask, const uint32_t* __restrict__ offs, const Tag tag,
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(kThreads) scatter(const uint64_t* __restrict__
 
 inline unsigned scatter_grid(unsigned tiles) { return (tiles + kXcds - 1) / kXcds * kXcds; }
 
-template <bool PAIRS, bool TAG>
+template <bool PAIRS, int TAG>
 void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint64_t* b, const float* va, float* vb, int64_t n,
                     int shift, uint32_t mask, int nb, const uint32_t* hist, const Tag& tag) {
     const bool hi = shift >= 32;
@@ -461,8 +463,8 @@ void launch_scatter(unsigned tiles, hipStream_t stream, const uint64_t* a, uint6
 template <bool PAIRS, int GEN>
 void launch_scatter_gen(unsigned tiles, hipStream_t stream, uint64_t* b, float* vb, int64_t n, int shift, uint32_t mask, int nb,
                         const uint32_t* hist, const RecordSource& gen) {
-    if (nb == 7) scatter<PAIRS, false, 7, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
-    else scatter<PAIRS, false, 8, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
+    if (nb == 7) scatter<PAIRS, 0, 7, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
+    else scatter<PAIRS, 0, 8, false, GEN><<<scatter_grid(tiles), kThreads, 0, stream>>>(nullptr, b, nullptr, vb, n, shift, mask, hist, Tag{}, gen, int64_t(tiles));
 }
 
 inline size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
@@ -516,9 +518,10 @@ hipError_t sort(uint64_t* a, uint64_t* b, float* va, float* vb, int64_t n, int f
                 else launch_scatter_gen<false, 1>(unsigned(tiles), stream, b, vb, n, shift, mask, nb, hist, *gen);
             }
         }
-        else if (pairs) launch_scatter<true, false>(unsigned(tiles), stream, a, b, va, vb, n, shift, mask, nb, hist, Tag{});
-        else if (tag && done == 0) launch_scatter<false, true>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, *tag);
-        else launch_scatter<false, false>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, Tag{});
+        else if (pairs) launch_scatter<true, 0>(unsigned(tiles), stream, a, b, va, vb, n, shift, mask, nb, hist, Tag{});
+        else if (tag && done == 0 && tag->counts) launch_scatter<false, 2>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, *tag);
+        else if (tag && done == 0) launch_scatter<false, 1>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, *tag);
+        else launch_scatter<false, 0>(unsigned(tiles), stream, a, b, nullptr, nullptr, n, shift, mask, nb, hist, Tag{});
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         uint64_t* t = a; a = b; b = t;
